@@ -1,0 +1,180 @@
+// Fused anti-aliased SnakeBeta activation: up x2 (12-tap kaiser-sinc, replicate pad) -> SnakeBeta
+// (log-scale alpha/beta) -> down x2 (12-tap, replicate pad 5/6), one pass over HBM.
+//
+// Replaces the reference's only native kernel, `anti_alias_activation_forward`
+// (alias_free_activation/cuda/anti_alias_activation_cuda.cu:43-179, launcher :181-209, entry
+// `fwd_cuda` :212-246) and is numerically the TORCH path the CPU reference runs
+// (alias_free_activation/torch/act.py:25-30, resample.py:28-37, filter.py:94-101,
+// activations.py:113-118) -- i.e. the replicate padding of the down-sampler is applied to the
+// ACTIVATED up-sampled signal, exactly as torch does.
+//
+// Index form (oracle/vocoder.py restates the same):
+//   u[2j]   = 2*sum_{q<6} f[2q+1]*x[cl(j+2-q)]      u[2j+1] = 2*sum_{q<6} f[2q]*x[cl(j+3-q)]
+//   v[m]    = u[m] + 1/(e^beta + 1e-9) * sin(u[m]*e^alpha)^2
+//   out[t]  = sum_{k<12} g[k]*v[cl2(2t+k-5)]
+//           = sum_{q<6} g[2q+1]*ve[t+q-2] + g[2q]*vo[t+q-3]      (ve[j]=v[2j], vo[j]=v[2j+1])
+//
+// CDNA4 mapping: one 256-thread workgroup per (row, 1024-sample tile).  The x tile (+8 halo,
+// index-clamped = replicate pad) is staged in LDS with coalesced dword loads; the up-sampled,
+// activated signal is split into its even/odd polyphase arrays in LDS so that both FIR passes
+// read unit-stride, 16-byte-aligned ds_read_b128 (a stride-2 read of an interleaved array
+// would be a 2-way bank conflict on every access); each thread produces 4 adjacent outputs and
+// stores them as one 16-byte global store.  HBM traffic = 1 read + 1 write per element.
+#include "common.h"
+
+namespace idxtts {
+
+constexpr int AA_TILE = 1024;   // outputs per workgroup (256 threads x 4)
+constexpr int AA_XH = 8;        // x halo each side (>= 6 needed, 8 keeps float4 alignment)
+constexpr int AA_VH = 4;        // polyphase halo each side (>= 3 needed)
+
+struct AAParams {
+  const float* x;
+  float* y;
+  const float* up_f;     // [12]
+  const float* down_f;   // [12]
+  const float* log_alpha;  // [C]
+  const float* log_beta;   // [C]
+  int C, T;
+};
+
+__device__ __forceinline__ float snake(float u, float a, float inv_b) {
+  const float s = sinf(u * a);
+  return u + inv_b * (s * s);
+}
+
+__global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
+  __shared__ __attribute__((aligned(16))) float xs[AA_TILE + 2 * AA_XH];
+  __shared__ __attribute__((aligned(16))) float ve[AA_TILE + 2 * AA_VH];
+  __shared__ __attribute__((aligned(16))) float vo[AA_TILE + 2 * AA_VH];
+
+  const int tid = threadIdx.x;
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int T = p.T;
+  const int t0 = blockIdx.x * AA_TILE;
+  const size_t row = ((size_t)b * p.C + c) * T;
+  const float* __restrict__ x = p.x + row;
+
+  // filters and per-channel constants (wave-uniform -> scalar registers)
+  float fe[6], fo[6], ge[6], go[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    fe[q] = 2.0f * p.up_f[2 * q + 1];   // even outputs use odd taps (x2 gain folded in)
+    fo[q] = 2.0f * p.up_f[2 * q];
+    ge[q] = p.down_f[2 * q + 1];        // taps that hit even v
+    go[q] = p.down_f[2 * q];
+  }
+  const float a = expf(p.log_alpha[c]);
+  const float inv_b = 1.0f / (expf(p.log_beta[c]) + 1e-9f);
+
+  // ---- phase 1: x tile with replicate (clamped) halo ----
+  for (int i = tid; i < AA_TILE + 2 * AA_XH; i += 256) {
+    int t = t0 - AA_XH + i;
+    t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+    xs[i] = x[t];
+  }
+  __syncthreads();
+
+  // ---- phase 2: polyphase up-sample + SnakeBeta into ve/vo (local index = j - (t0 - AA_VH)) ----
+  const int j0 = t0 - AA_VH;
+  for (int G = tid; G < (AA_TILE + 2 * AA_VH) / 4; G += 256) {
+    const int jg = j0 + 4 * G;
+    float e[4], o[4];
+    if (jg >= 0 && jg + 3 < T) {
+      // x[j-3 .. j+6] for the 4 j's = xs[4G+1 .. 4G+10]
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(&xs[4 * G]);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(&xs[4 * G + 4]);
+      const f32x4 x2 = *reinterpret_cast<const f32x4*>(&xs[4 * G + 8]);
+      const float w[12] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3], x2[0], x2[1], x2[2], x2[3]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // j = jg+i ; x[j+2-q] = w[i+6-q] ; x[j+3-q] = w[i+7-q]
+        float ue = 0.f, uo = 0.f;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          ue = fmaf(fe[q], w[i + 6 - q], ue);
+          uo = fmaf(fo[q], w[i + 7 - q], uo);
+        }
+        e[i] = snake(ue, a, inv_b);
+        o[i] = snake(uo, a, inv_b);
+      }
+    } else {
+      // sequence edge: v is replicate-padded in ITS index space (m clamped to [0, 2T-1])
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = jg + i;
+        const int jj = j < 0 ? 0 : (j > T - 1 ? T - 1 : j);
+        const int base = jj - (t0 - AA_XH);           // xs index of x[jj]
+        float ue = 0.f, uo = 0.f;
+        if (base - 3 >= 0 && base + 3 < AA_TILE + 2 * AA_XH) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            ue = fmaf(fe[q], xs[base + 2 - q], ue);
+            uo = fmaf(fo[q], xs[base + 3 - q], uo);
+          }
+        }
+        float ev = snake(ue, a, inv_b), ov = snake(uo, a, inv_b);
+        if (j < 0) ov = ev;          // v[clamp(2j+1)] = v[0]
+        if (j > T - 1) ev = ov;      // v[clamp(2j)]   = v[2T-1]
+        e[i] = ev;
+        o[i] = ov;
+      }
+    }
+    *reinterpret_cast<f32x4*>(&ve[4 * G]) = f32x4{e[0], e[1], e[2], e[3]};
+    *reinterpret_cast<f32x4*>(&vo[4 * G]) = f32x4{o[0], o[1], o[2], o[3]};
+  }
+  __syncthreads();
+
+  // ---- phase 3: polyphase down-sample, 4 outputs per thread ----
+  const int t = t0 + 4 * tid;
+  if (t >= T) return;
+  float ew[12], ow[12];
+  {
+    const f32x4 e0 = *reinterpret_cast<const f32x4*>(&ve[4 * tid]);
+    const f32x4 e1 = *reinterpret_cast<const f32x4*>(&ve[4 * tid + 4]);
+    const f32x4 e2 = *reinterpret_cast<const f32x4*>(&ve[4 * tid + 8]);
+    const f32x4 o0 = *reinterpret_cast<const f32x4*>(&vo[4 * tid]);
+    const f32x4 o1 = *reinterpret_cast<const f32x4*>(&vo[4 * tid + 4]);
+    const f32x4 o2 = *reinterpret_cast<const f32x4*>(&vo[4 * tid + 8]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ew[i] = e0[i]; ew[4 + i] = e1[i]; ew[8 + i] = e2[i];
+      ow[i] = o0[i]; ow[4 + i] = o1[i]; ow[8 + i] = o2[i];
+    }
+  }
+  float out[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // local index of ve[t+i+q-2] = (t+i+q-2) - j0 = 4*tid + i + q + 2 ; vo[t+i+q-3] -> 4*tid + i + q + 1
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      acc = fmaf(go[q], ow[i + q + 1], acc);
+      acc = fmaf(ge[q], ew[i + q + 2], acc);
+    }
+    out[i] = acc;
+  }
+  float* __restrict__ y = p.y + row;
+  if ((T & 3) == 0) {
+    *reinterpret_cast<f32x4*>(&y[t]) = f32x4{out[0], out[1], out[2], out[3]};
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (t + i < T) y[t + i] = out[i];
+  }
+}
+
+int aa_act_forward(float* y, const float* x, const float* up_f, const float* down_f, const float* log_alpha,
+                   const float* log_beta, int B, int C, int T, hipStream_t stream) {
+  IDX_CHECK(y && x && up_f && down_f && log_alpha && log_beta, "null pointer");
+  IDX_CHECK(y != x, "aa_act is not in-place safe (tile halos)");
+  if (B == 0 || C == 0 || T == 0) return 0;   // reference: seq_len == 0 -> no-op (.cu:193)
+  IDX_CHECK(C <= 65535 && B <= 65535, "grid y/z limit");
+  AAParams p{x, y, up_f, down_f, log_alpha, log_beta, C, T};
+  dim3 grid(cdiv(T, AA_TILE), C, B);
+  hipLaunchKernelGGL(aa_act_kernel, grid, dim3(256), 0, stream, p);
+  IDX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace idxtts

@@ -1,0 +1,177 @@
+// extern "C" surface of libidxtts_hip (declared in include/idxtts.h).  Nothing here throws.
+#include <cstring>
+#include <new>
+
+#include "../../include/idxtts.h"
+#include "bigvgan.h"
+#include "conv1d.h"
+#include "ctx.h"
+
+namespace idxtts {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(const char* file, int line, const std::string& msg) {
+  const char* base = std::strrchr(file, '/');
+  g_last_error = std::string(base ? base + 1 : file) + ":" + std::to_string(line) + ": " + msg;
+  return 1;
+}
+
+int aa_act_forward(float* y, const float* x, const float* up_f, const float* down_f, const float* log_alpha,
+                   const float* log_beta, int B, int C, int T, hipStream_t stream);
+
+}  // namespace idxtts
+
+using namespace idxtts;
+
+struct idxtts_conv1d {
+  ConvWeights w;
+  DeviceArena arena;
+  int Cout = 0;
+};
+
+#define API_BEGIN try {
+#define API_END                                                        \
+  }                                                                    \
+  catch (const std::exception& e) { return fail(__FILE__, __LINE__, std::string("exception: ") + e.what()); } \
+  catch (...) { return fail(__FILE__, __LINE__, "unknown exception"); }
+
+extern "C" {
+
+int idxtts_version(void) { return 100; }
+
+const char* idxtts_last_error(void) { return g_last_error.c_str(); }
+
+int idxtts_aa_act_fwd(float* out, const float* in, const float* up_filter, const float* down_filter,
+                      const float* log_alpha, const float* log_beta, int B, int C, int T, int dtype, void* stream) {
+  API_BEGIN
+  IDX_CHECK(dtype == IDXTTS_DTYPE_F32, "only float32 is implemented");
+  IDX_CHECK(B >= 0 && C >= 0 && T >= 0, "negative shape");
+  return aa_act_forward(out, in, up_filter, down_filter, log_alpha, log_beta, B, C, T, static_cast<hipStream_t>(stream));
+  API_END
+}
+
+// copies `n` floats from a host-or-device pointer into a host vector
+static int fetch(const float* src, size_t n, std::vector<float>* dst) {
+  dst->resize(n);
+  if (n) IDX_HIP(hipMemcpy(dst->data(), src, n * sizeof(float), hipMemcpyDefault));
+  return 0;
+}
+
+int idxtts_conv1d_create(const float* weight, const float* bias, int Cout, int Cin, int K, int transposed_stride,
+                         idxtts_conv1d** out) {
+  API_BEGIN
+  IDX_CHECK(weight && out, "null pointer");
+  IDX_CHECK(Cout > 0 && Cin > 0 && K > 0 && transposed_stride >= 1, "bad shape");
+  std::unique_ptr<idxtts_conv1d> c(new idxtts_conv1d());
+  std::vector<float> hw, hb;
+  if (fetch(weight, (size_t)Cout * Cin * K, &hw)) return 1;
+  c->Cout = Cout;
+  c->w.Cin = Cin;
+  c->w.nchunk = cdiv(Cin, CONV_KC);
+  c->w.ups = transposed_stride;
+  if (transposed_stride > 1) {
+    IDX_CHECK(K == 2 * transposed_stride, "ConvTranspose1d kernel must be 2*stride");
+    c->w.M = Cout * transposed_stride;
+    c->w.K = 3;
+  } else {
+    c->w.M = Cout;
+    c->w.K = K;
+  }
+  std::vector<float> packed(conv_packed_floats(c->w.M, Cin, c->w.K));
+  if (transposed_stride > 1) pack_conv_transpose1d(packed.data(), hw.data(), Cin, Cout, K, transposed_stride);
+  else pack_conv1d(packed.data(), hw.data(), Cout, Cin, K);
+  float* d = nullptr;
+  if (c->arena.upload(packed.data(), packed.size(), &d)) return 1;
+  c->w.wp = d;
+  if (bias) {
+    if (fetch(bias, Cout, &hb)) return 1;
+    if (c->arena.upload(hb.data(), hb.size(), &d)) return 1;
+    c->w.bias = d;
+  }
+  *out = c.release();
+  return 0;
+  API_END
+}
+
+int idxtts_conv1d_fwd(const idxtts_conv1d* conv, const float* x, float* y, const float* residual, int B, int T,
+                      int dilation, int pad_left, int pad_mode, float scale, int accumulate, void* stream) {
+  API_BEGIN
+  IDX_CHECK(conv, "null handle");
+  if (B == 0 || T == 0) return 0;
+  ConvArgs a;
+  a.x = x; a.y = y; a.res = residual; a.B = B; a.T = T; a.dil = dilation; a.pad_left = pad_left;
+  a.pad_mode = pad_mode; a.scale = scale; a.accum = accumulate;
+  return conv1d_forward(conv->w, a, static_cast<hipStream_t>(stream));
+  API_END
+}
+
+int idxtts_conv1d_destroy(idxtts_conv1d* conv) {
+  delete conv;
+  return 0;
+}
+
+int idxtts_ctx_load_tensor(idxtts_ctx* ctx, const char* name, const float* data, const int64_t* shape, int ndim) {
+  API_BEGIN
+  IDX_CHECK(ctx && name && shape, "null pointer");
+  IDX_CHECK(!ctx->finalized, "context already finalized");
+  IDX_CHECK(ndim >= 0 && ndim <= 8, "ndim");
+  const std::string key(name);
+  if (!ctx->model->accepts(key)) IDX_FAIL("unknown tensor name '" + key + "'");
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  const int64_t n = t.numel();
+  IDX_CHECK(n >= 0, "negative numel");
+  IDX_CHECK(n == 0 || data, "null data");
+  if (fetch(data, (size_t)n, &t.data)) return 1;
+  ctx->tensors[key] = std::move(t);
+  return 0;
+  API_END
+}
+
+int idxtts_ctx_finalize(idxtts_ctx* ctx) {
+  API_BEGIN
+  IDX_CHECK(ctx, "null ctx");
+  IDX_CHECK(!ctx->finalized, "context already finalized");
+  if (ctx->model->finalize(ctx->tensors, ctx->arena)) return 1;
+  ctx->tensors.clear();
+  ctx->finalized = true;
+  return 0;
+  API_END
+}
+
+int idxtts_ctx_destroy(idxtts_ctx* ctx) {
+  delete ctx;
+  return 0;
+}
+
+int idxtts_bigvgan_create(const idxtts_bigvgan_config* cfg, idxtts_ctx** out) {
+  API_BEGIN
+  IDX_CHECK(cfg && out, "null pointer");
+  std::unique_ptr<idxtts_ctx> ctx(new idxtts_ctx());
+  ctx->model.reset(new BigVGANModel(*cfg));
+  *out = ctx.release();
+  return 0;
+  API_END
+}
+
+size_t idxtts_bigvgan_workspace_bytes(const idxtts_ctx* ctx, int B, int Tm) {
+  if (!ctx || B <= 0 || Tm <= 0) return 0;
+  auto* m = dynamic_cast<const BigVGANModel*>(ctx->model.get());
+  return m ? m->workspace_bytes(B, Tm) : 0;
+}
+
+int idxtts_bigvgan_fwd(idxtts_ctx* ctx, const float* mel, float* wav, int B, int Tm, void* workspace,
+                       size_t workspace_bytes, int clamp, int stage_idx, float* stage_out, void* stream) {
+  API_BEGIN
+  IDX_CHECK(ctx, "null ctx");
+  IDX_CHECK(ctx->finalized, "context not finalized");
+  auto* m = dynamic_cast<BigVGANModel*>(ctx->model.get());
+  IDX_CHECK(m, "not a BigVGAN context");
+  IDX_CHECK(B >= 0 && Tm >= 0, "negative shape");
+  return m->forward(mel, wav, B, Tm, workspace, workspace_bytes, clamp, stage_idx, stage_out, static_cast<hipStream_t>(stream));
+  API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+"""ctypes binding of libidxtts_hip.so (the C ABI declared in include/idxtts.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, importing an
+op raises -- loudly -- instead of routing through PyTorch or the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libidxtts_hip.so")
+
+# every symbol include/idxtts.h declares (tests/test_abi.py checks the list against the header)
+SYMBOLS = [
+    "idxtts_version", "idxtts_last_error", "idxtts_aa_act_fwd",
+    "idxtts_conv1d_create", "idxtts_conv1d_fwd", "idxtts_conv1d_destroy",
+    "idxtts_ctx_load_tensor", "idxtts_ctx_finalize", "idxtts_ctx_destroy",
+    "idxtts_bigvgan_create", "idxtts_bigvgan_workspace_bytes", "idxtts_bigvgan_fwd",
+]
+
+
+class BigVGANConfigC(ctypes.Structure):
+    _fields_ = [
+        ("num_mels", c_int), ("upsample_initial_channel", c_int), ("num_upsamples", c_int),
+        ("upsample_rates", c_int * 8), ("upsample_kernel_sizes", c_int * 8),
+        ("num_kernels", c_int), ("resblock_kernel_sizes", c_int * 4),
+        ("resblock_dilations", (c_int * 3) * 4),
+    ]
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and return the library; raise if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libidxtts_hip.so not found at {LIB_PATH}: build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C index-tts_amd/csrc`). "
+            "There is no CPU/PyTorch fallback for the HIP path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.idxtts_version.restype = c_int
+    lib.idxtts_last_error.restype = c_char_p
+    lib.idxtts_aa_act_fwd.argtypes = [c_void_p] * 6 + [c_int] * 4 + [c_void_p]
+    lib.idxtts_conv1d_create.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_void_p)]
+    lib.idxtts_conv1d_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                      c_float, c_int, c_void_p]
+    lib.idxtts_conv1d_destroy.argtypes = [c_void_p]
+    lib.idxtts_ctx_load_tensor.argtypes = [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]
+    lib.idxtts_ctx_finalize.argtypes = [c_void_p]
+    lib.idxtts_ctx_destroy.argtypes = [c_void_p]
+    lib.idxtts_bigvgan_create.argtypes = [POINTER(BigVGANConfigC), POINTER(c_void_p)]
+    lib.idxtts_bigvgan_workspace_bytes.argtypes = [c_void_p, c_int, c_int]
+    lib.idxtts_bigvgan_workspace_bytes.restype = c_size_t
+    lib.idxtts_bigvgan_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_int, c_int,
+                                       c_void_p, c_void_p]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
+        if fn.restype is c_int and name not in ("idxtts_version",):
+            pass
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().idxtts_last_error()
+        raise RuntimeError("libidxtts_hip: " + (msg.decode("utf-8", "replace") if msg else f"error {rc}"))
+
+
+def ptr(t) -> c_void_p:
+    """Device (or host) pointer of a contiguous float32 torch tensor, or NULL for None."""
+    if t is None:
+        return c_void_p(0)
+    return c_void_p(t.data_ptr())
+
+
+def current_stream() -> c_void_p:
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def load_state_dict(ctx: c_void_p, state_dict) -> None:
+    """Hand every tensor of a (reference-layout) state dict to the context, then finalize it."""
+    import numpy as np
+    import torch
+    lib = load()
+    for name, value in state_dict.items():
+        if isinstance(value, torch.Tensor):
+            arr = value.detach().to(dtype=torch.float32).contiguous()
+            shape = tuple(arr.shape)
+            dptr = c_void_p(arr.data_ptr())
+        else:
+            arr = np.ascontiguousarray(value, dtype=np.float32)
+            shape = arr.shape
+            dptr = c_void_p(arr.ctypes.data)
+        cshape = (c_int64 * max(1, len(shape)))(*shape)
+        check(lib.idxtts_ctx_load_tensor(ctx, name.encode(), dptr, cshape, len(shape)))
+    check(lib.idxtts_ctx_finalize(ctx))

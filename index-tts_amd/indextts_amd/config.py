@@ -1,0 +1,147 @@
+"""Model hyper-parameters of the IndexTTS-2 hot path.
+
+Values mirror the reference's `checkpoints/config.yaml` (gpt: lines 14-44, s2mel: 53-108) and
+`indextts/s2mel/modules/bigvgan/config.json` (lines 11-21, 41-48).  `tiny()` variants keep the
+same structure at reduced width so that CPU oracles and golden fixtures finish in seconds.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Tuple
+
+
+@dataclass(frozen=True)
+class BigVGANConfig:
+    num_mels: int = 80
+    upsample_initial_channel: int = 1536
+    upsample_rates: Tuple[int, ...] = (4, 4, 2, 2, 2, 2)
+    upsample_kernel_sizes: Tuple[int, ...] = (8, 8, 4, 4, 4, 4)
+    resblock_kernel_sizes: Tuple[int, ...] = (3, 7, 11)
+    resblock_dilation_sizes: Tuple[Tuple[int, ...], ...] = ((1, 3, 5), (1, 3, 5), (1, 3, 5))
+    sampling_rate: int = 22050
+    hop_size: int = 256
+
+    @property
+    def num_upsamples(self) -> int:
+        return len(self.upsample_rates)
+
+    @property
+    def num_kernels(self) -> int:
+        return len(self.resblock_kernel_sizes)
+
+    def channels(self, stage: int) -> int:
+        """Channel count after `stage` up-samplings (stage 0 = conv_pre output)."""
+        return self.upsample_initial_channel // (2 ** stage)
+
+    @property
+    def total_upsample(self) -> int:
+        n = 1
+        for u in self.upsample_rates:
+            n *= u
+        return n
+
+    @staticmethod
+    def tiny(initial_channel: int = 64) -> "BigVGANConfig":
+        return BigVGANConfig(upsample_initial_channel=initial_channel)
+
+
+@dataclass(frozen=True)
+class GPTConfig:
+    model_dim: int = 1280
+    heads: int = 20
+    layers: int = 24
+    number_text_tokens: int = 12000   # text vocab = number_text_tokens + 1 (model_v2.py:381)
+    number_mel_codes: int = 8194
+    start_mel_token: int = 8192
+    stop_mel_token: int = 8193
+    start_text_token: int = 0
+    stop_text_token: int = 1
+    max_mel_tokens: int = 1815
+    max_text_tokens: int = 600
+    cond_latents: int = 32            # perceiver latents; +2 speed embeddings = 34 prefix rows
+
+    @property
+    def head_dim(self) -> int:
+        return self.model_dim // self.heads
+
+    @property
+    def ffn_dim(self) -> int:
+        return 4 * self.model_dim
+
+    @property
+    def mel_pos_len(self) -> int:     # max_mel_tokens + 2 + max_conditioning_inputs (model_v2.py:404)
+        return self.max_mel_tokens + 3
+
+    @property
+    def text_pos_len(self) -> int:    # max_text_tokens + 2
+        return self.max_text_tokens + 2
+
+    @staticmethod
+    def tiny() -> "GPTConfig":
+        return GPTConfig(model_dim=128, heads=4, layers=3, number_text_tokens=300,
+                         number_mel_codes=258, start_mel_token=256, stop_mel_token=257,
+                         max_mel_tokens=120, max_text_tokens=60, cond_latents=6)
+
+
+@dataclass(frozen=True)
+class S2MelConfig:
+    # DiT (config.yaml:80-101)
+    hidden_dim: int = 512
+    num_heads: int = 8
+    depth: int = 13
+    in_channels: int = 80
+    content_dim: int = 512
+    style_dim: int = 192
+    block_size: int = 16384          # rotary table length (diffusion_transformer.py:113)
+    rope_base: float = 10000.0
+    norm_eps: float = 1e-5
+    # WaveNet (config.yaml:102-108)
+    wn_hidden: int = 512
+    wn_layers: int = 8
+    wn_kernel: int = 5
+    wn_dilation_rate: int = 1
+    # length regulator (config.yaml:67-78)
+    lr_channels: int = 512
+    lr_in_channels: int = 1024
+    lr_num_convs: int = 4            # len(sampling_ratios)
+    # gpt_layer (commons.py:413)
+    gpt_dim: int = 1280
+    gpt_layer_dims: Tuple[int, ...] = (256, 128, 1024)
+    # semantic codec (config.yaml:46-52)
+    codebook_size: int = 8192
+    codebook_dim: int = 8
+    codec_hidden: int = 1024
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_dim // self.num_heads
+
+    @property
+    def ffn_dim(self) -> int:        # gpt_fast ModelArgs.__post_init__ (model.py:58-64)
+        n_hidden = int(2 * (4 * self.hidden_dim) / 3)
+        return n_hidden if n_hidden % 256 == 0 else n_hidden + 256 - (n_hidden % 256)
+
+    @staticmethod
+    def tiny() -> "S2MelConfig":
+        return S2MelConfig(hidden_dim=64, num_heads=2, depth=5, in_channels=16, content_dim=64,
+                           style_dim=24, block_size=512, wn_hidden=64, wn_layers=3,
+                           lr_channels=64, lr_in_channels=96, gpt_dim=128,
+                           gpt_layer_dims=(48, 32, 96), codebook_size=256, codebook_dim=8,
+                           codec_hidden=96)
+
+
+@dataclass(frozen=True)
+class PipelineConfig:
+    gpt: GPTConfig = field(default_factory=GPTConfig)
+    s2mel: S2MelConfig = field(default_factory=S2MelConfig)
+    bigvgan: BigVGANConfig = field(default_factory=BigVGANConfig)
+    code_to_frame: float = 1.72      # infer_v2.py:844
+    diffusion_steps: int = 20        # TARS_DIFFUSION_STEPS default (infer_v2.py:125)
+    cfg_rate: float = 0.7            # TARS_CFG_RATE default (infer_v2.py:126)
+
+    @staticmethod
+    def tiny() -> "PipelineConfig":
+        g, s = GPTConfig.tiny(), S2MelConfig.tiny()
+        return PipelineConfig(gpt=g, s2mel=s,
+                              bigvgan=BigVGANConfig(num_mels=s.in_channels, upsample_initial_channel=64),
+                              diffusion_steps=3)
