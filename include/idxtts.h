@@ -88,6 +88,16 @@ size_t idxtts_bigvgan_workspace_bytes(const idxtts_ctx* ctx, int B, int Tm);
 int idxtts_bigvgan_fwd(idxtts_ctx* ctx, const float* mel, float* wav, int B, int Tm, void* workspace,
                        size_t workspace_bytes, int clamp, int stage_idx, float* stage_out, void* stream);
 
+/* ---- per-kernel timing for the benchmark's roofline report ------------------------------------------
+ * When enabled, every kernel launch is bracketed by HIP events on its own stream and the library
+ * accumulates, per kernel family, the launch count, elapsed milliseconds and the ALGORITHMIC flops /
+ * bytes of the launches (DESIGN.md "work units").  Enabling resets the accumulators.  Not for use
+ * inside a timed region (event records serialise nothing but add host work per launch). */
+int idxtts_profile_enable(int on);
+int idxtts_profile_num_kernels(void);
+const char* idxtts_profile_kernel_name(int index);
+int idxtts_profile_read(int index, double* total_ms, double* flops, double* bytes, long* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,7 @@
 // would be a 2-way bank conflict on every access); each thread produces 4 adjacent outputs and
 // stores them as one 16-byte global store.  HBM traffic = 1 read + 1 write per element.
 #include "common.h"
+#include "prof.h"
 
 namespace idxtts {
 
@@ -166,12 +167,13 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
 
 int aa_act_forward(float* y, const float* x, const float* up_f, const float* down_f, const float* log_alpha,
                    const float* log_beta, int B, int C, int T, hipStream_t stream) {
+  if (B == 0 || C == 0 || T == 0) return 0;   // reference: seq_len == 0 -> no-op (.cu:193)
   IDX_CHECK(y && x && up_f && down_f && log_alpha && log_beta, "null pointer");
   IDX_CHECK(y != x, "aa_act is not in-place safe (tile halos)");
-  if (B == 0 || C == 0 || T == 0) return 0;   // reference: seq_len == 0 -> no-op (.cu:193)
   IDX_CHECK(C <= 65535 && B <= 65535, "grid y/z limit");
   AAParams p{x, y, up_f, down_f, log_alpha, log_beta, C, T};
   dim3 grid(cdiv(T, AA_TILE), C, B);
+  ProfScope prof(PROF_AA_ACT, stream, 0.0, 8.0 * B * C * (double)T);   // one read + one write per element
   hipLaunchKernelGGL(aa_act_kernel, grid, dim3(256), 0, stream, p);
   IDX_LAUNCH_CHECK();
   return 0;

@@ -19,6 +19,7 @@
 // the n-tiles n = x (mod 8) and walks them m-tile-major; the 32 CUs of an XCD then stream
 // the SAME weight slice through their shared 4 MiB L2 while their x tiles differ.
 #include "conv1d.h"
+#include "prof.h"
 
 namespace idxtts {
 
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvKP p) {
   }
 }
 
-template <int TM, int TN, int WGM, int WGN>
+template <int TM, int TN, int WGM, int WGN, int CAT>
 static int launch_conv(const ConvWeights& w, const ConvArgs& a, hipStream_t stream) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, NSUB = TM * WGM;
   ConvKP p;
@@ -281,7 +282,17 @@ static int launch_conv(const ConvWeights& w, const ConvArgs& a, hipStream_t stre
     IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p);
+  {
+    // algorithmic work: 2*Cout*Cin*taps per output sample (a transposed conv has Kt/u = 2 live taps
+    // per output, not the 3 the packed form multiplies); bytes = x + y (+ residual / accumulate) + weights once
+    const double cout = (double)(w.M / w.ups), tout = (double)a.T * w.ups * a.B;
+    const double taps = w.ups > 1 ? 2.0 : (double)w.K;
+    const double flops = 2.0 * cout * w.Cin * taps * tout;
+    const double bytes = 4.0 * ((double)a.B * w.Cin * a.T + cout * tout * (1.0 + (a.res ? 1.0 : 0.0) + (a.accum ? 1.0 : 0.0)) +
+                                cout * w.Cin * (w.ups > 1 ? 2.0 * w.ups : (double)w.K));
+    ProfScope prof(CAT, stream, flops, bytes);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p);
+  }
   IDX_LAUNCH_CHECK();
   return 0;
 }
@@ -290,10 +301,10 @@ int conv1d_forward(const ConvWeights& w, const ConvArgs& a, hipStream_t stream) 
   IDX_CHECK(w.wp && a.x && a.y, "null pointer");
   IDX_CHECK(a.B > 0 && a.T > 0, "empty shape");
   if (a.pad_mode == PAD_REFLECT) IDX_CHECK(a.T > (w.K - 1) * a.dil, "reflect pad needs T > halo");
-  if (w.M > 96) return launch_conv<2, 2, 2, 2>(w, a, stream);   // 128 x 128
-  if (w.M > 64) return launch_conv<3, 2, 1, 4>(w, a, stream);   //  96 x 256
-  if (w.M > 32) return launch_conv<2, 2, 1, 4>(w, a, stream);   //  64 x 256
-  return launch_conv<1, 4, 1, 4>(w, a, stream);                 //  32 x 512
+  if (w.M > 96) return launch_conv<2, 2, 2, 2, PROF_CONV_128x128>(w, a, stream);   // 128 x 128
+  if (w.M > 64) return launch_conv<3, 2, 1, 4, PROF_CONV_96x256>(w, a, stream);   //  96 x 256
+  if (w.M > 32) return launch_conv<2, 2, 1, 4, PROF_CONV_64x256>(w, a, stream);   //  64 x 256
+  return launch_conv<1, 4, 1, 4, PROF_CONV_32x512>(w, a, stream);                 //  32 x 512
 }
 
 }  // namespace idxtts

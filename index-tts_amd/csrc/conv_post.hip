@@ -4,6 +4,7 @@
 // so this is a VALU kernel, not an MFMA one: each thread keeps 4 adjacent outputs and walks the
 // channels with 16-byte loads (t-4, t, t+4 windows; the overlap is served by L1/L2).
 #include "common.h"
+#include "prof.h"
 
 namespace idxtts {
 
@@ -63,6 +64,7 @@ int conv_post_forward(float* y, const float* x, const float* w, int B, int C, in
   if (B == 0 || T == 0) return 0;
   ConvPostParams p{x, w, y, C, T, clamp};
   dim3 grid(cdiv(T, 1024), B);
+  ProfScope prof(PROF_CONV_POST, stream, 14.0 * B * C * (double)T, 4.0 * B * (C + 1.0) * (double)T);
   hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), (size_t)C * 7 * sizeof(float), stream, p);
   IDX_LAUNCH_CHECK();
   return 0;

@@ -1,0 +1,91 @@
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/idxtts.h"
+#include "prof.h"
+
+namespace idxtts {
+
+static const char* kNames[PROF_NCAT] = {
+    "conv1d_mfma_128x128", "conv1d_mfma_96x256", "conv1d_mfma_64x256", "conv1d_mfma_32x512", "aa_act", "conv_post"};
+
+struct Rec { hipEvent_t a, b; int cat; };
+static std::mutex g_mu;
+static bool g_on = false;
+static std::vector<Rec> g_recs;            // launches recorded since enable
+static std::vector<hipEvent_t> g_pool;     // recycled events
+static double g_flops[PROF_NCAT], g_bytes[PROF_NCAT], g_ms[PROF_NCAT];
+static long g_count[PROF_NCAT];
+static hipEvent_t g_open[PROF_NCAT];
+
+const char* prof_name(int cat) { return (cat >= 0 && cat < PROF_NCAT) ? kNames[cat] : "?"; }
+bool prof_enabled() { return g_on; }
+
+static hipEvent_t get_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void prof_begin(int cat, hipStream_t stream, double flops, double bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipEvent_t a = get_event();
+  (void)hipEventRecord(a, stream);
+  g_open[cat] = a;
+  g_flops[cat] += flops;
+  g_bytes[cat] += bytes;
+  g_count[cat] += 1;
+}
+
+void prof_end(int cat, hipStream_t stream) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipEvent_t b = get_event();
+  (void)hipEventRecord(b, stream);
+  g_recs.push_back(Rec{g_open[cat], b, cat});
+}
+
+static void drain() {   // resolve recorded event pairs into per-family milliseconds
+  for (const Rec& r : g_recs) {
+    (void)hipEventSynchronize(r.b);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) g_ms[r.cat] += ms;
+    g_pool.push_back(r.a);
+    g_pool.push_back(r.b);
+  }
+  g_recs.clear();
+}
+
+}  // namespace idxtts
+
+using namespace idxtts;
+
+extern "C" {
+
+int idxtts_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (on) {
+    drain();
+    for (int c = 0; c < PROF_NCAT; ++c) { g_flops[c] = g_bytes[c] = g_ms[c] = 0.0; g_count[c] = 0; }
+  }
+  g_on = on != 0;
+  return 0;
+}
+
+int idxtts_profile_num_kernels(void) { return PROF_NCAT; }
+
+const char* idxtts_profile_kernel_name(int index) { return prof_name(index); }
+
+int idxtts_profile_read(int index, double* total_ms, double* flops, double* bytes, long* launches) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (index < 0 || index >= PROF_NCAT) return 1;
+  drain();
+  if (total_ms) *total_ms = g_ms[index];
+  if (flops) *flops = g_flops[index];
+  if (bytes) *bytes = g_bytes[index];
+  if (launches) *launches = g_count[index];
+  return 0;
+}
+
+}  // extern "C"

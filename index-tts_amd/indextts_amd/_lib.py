@@ -18,6 +18,7 @@ SYMBOLS = [
     "idxtts_conv1d_create", "idxtts_conv1d_fwd", "idxtts_conv1d_destroy",
     "idxtts_ctx_load_tensor", "idxtts_ctx_finalize", "idxtts_ctx_destroy",
     "idxtts_bigvgan_create", "idxtts_bigvgan_workspace_bytes", "idxtts_bigvgan_fwd",
+    "idxtts_profile_enable", "idxtts_profile_num_kernels", "idxtts_profile_kernel_name", "idxtts_profile_read",
 ]
 
 
@@ -59,10 +60,13 @@ def load() -> ctypes.CDLL:
     lib.idxtts_bigvgan_workspace_bytes.restype = c_size_t
     lib.idxtts_bigvgan_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_int, c_int,
                                        c_void_p, c_void_p]
+    lib.idxtts_profile_enable.argtypes = [c_int]
+    lib.idxtts_profile_kernel_name.argtypes = [c_int]
+    lib.idxtts_profile_kernel_name.restype = c_char_p
+    lib.idxtts_profile_read.argtypes = [c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_double),
+                                        POINTER(ctypes.c_double), POINTER(ctypes.c_long)]
     for name in SYMBOLS:
-        fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
-        if fn.restype is c_int and name not in ("idxtts_version",):
-            pass
+        getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
     _lib = lib
     return lib
 
@@ -102,3 +106,20 @@ def load_state_dict(ctx: c_void_p, state_dict) -> None:
         cshape = (c_int64 * max(1, len(shape)))(*shape)
         check(lib.idxtts_ctx_load_tensor(ctx, name.encode(), dptr, cshape, len(shape)))
     check(lib.idxtts_ctx_finalize(ctx))
+
+
+def profile_enable(on: bool) -> None:
+    check(load().idxtts_profile_enable(int(on)))
+
+
+def profile_read() -> dict:
+    """{kernel family: {"ms", "flops", "bytes", "launches"}} accumulated since profile_enable(True)."""
+    lib = load()
+    out = {}
+    for i in range(lib.idxtts_profile_num_kernels()):
+        ms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
+        check(lib.idxtts_profile_read(i, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n)))
+        if n.value:
+            out[lib.idxtts_profile_kernel_name(i).decode()] = {
+                "ms": ms.value, "flops": fl.value, "bytes": by.value, "launches": n.value}
+    return out
