@@ -46,7 +46,7 @@ def main() -> int:
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--frames", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=600, help="mel frames of the bounded CPU-baseline sample (B=1)")
+    ap.add_argument("--cpu-rows", type=int, default=1, help="batch rows of the workload the CPU baseline runs (bounded sample)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -139,22 +139,25 @@ def main() -> int:
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import vocoder as ov
-        cores = os.cpu_count() or 1
+        # the box's CPU share, not the host's core count (oversubscribing a cgroup quota stalls for minutes)
+        cores = max(1, min(16, len(os.sched_getaffinity(0)), os.cpu_count() or 1))
         torch.set_num_threads(cores)
-        cmel = torch.from_numpy(weights.synth_mel("bench/mel/rank0", 1, cfg.num_mels, args.cpu_frames))
+        rows = max(1, min(B, args.cpu_rows))
+        log(f"[bench] cpu baseline: oracle BigVGAN on [{rows},80,{Tm}] with {cores} threads ...")
+        cmel = mel[:rows].cpu()
         wt = {k: torch.from_numpy(v) for k, v in w.items()}
         with torch.no_grad():
             ov.bigvgan_forward(wt, cfg, cmel[:, :, :32])   # warm the thread pool
             c0 = time.perf_counter()
             cw = ov.bigvgan_forward(wt, cfg, cmel)
             cdt = time.perf_counter() - c0
-        caudio = cw.shape[-1] / cfg.sampling_rate
+        caudio = cw.shape[0] * cw.shape[-1] / cfg.sampling_rate
         # cross-check the GPU result on the same first row while we have it
-        gw = voc(mel[:1, :, : args.cpu_frames].contiguous()).cpu()
+        gw = voc(mel[:rows].contiguous()).cpu()
         err = (gw - cw).abs().max().item()
         log(f"[bench] cpu oracle: {caudio:.2f}s audio in {cdt:.2f}s on {cores} threads; max|gpu-cpu| on that sample = {err:.2e}")
         cpu_baseline = {"value": round(caudio / cdt, 4), "unit": "audio_s/s", "cores": cores, "kind": "port",
-                        "sample": f"oracle/vocoder.py BigVGAN fp32, 1 x [80 x {args.cpu_frames}] mel ({caudio:.2f} s audio), "
+                        "sample": f"oracle/vocoder.py BigVGAN fp32, {rows} x [80 x {Tm}] mels of the same batch ({caudio:.2f} s audio), "
                                   f"torch CPU {cores} threads", "max_abs_diff_vs_gpu": err}
 
     if rank == 0:
