@@ -88,6 +88,59 @@ size_t idxtts_bigvgan_workspace_bytes(const idxtts_ctx* ctx, int B, int Tm);
 int idxtts_bigvgan_fwd(idxtts_ctx* ctx, const float* mel, float* wav, int B, int Tm, void* workspace,
                        size_t workspace_bytes, int clamp, int stage_idx, float* stage_out, void* stream);
 
+/* ---- token-major building blocks (also used stand-alone by the tests) ------------------------------
+ * idxtts_linear: Y[M][N] = act(X[M][K] W^T + bias) (+ residual) on the fp32 matrix core.
+ * weight: [N][K] (torch nn.Linear) or, if weight_is_kn, [K][N] (HF Conv1D: model_v2.py:290 GPT2Model).
+ * act: 0 none, 1 gelu_new, 2 silu, 3 swiglu (rows packed [32 gate | 32 linear] blocks; Y is [M][N/2]), 4 mish. */
+typedef struct idxtts_linear idxtts_linear;
+int idxtts_linear_create(const float* weight, const float* bias /* may be NULL */, int N, int K, int weight_is_kn,
+                         idxtts_linear** out);
+int idxtts_linear_fwd(const idxtts_linear* lin, const float* x, int ldx, float* y, int ldy, const float* residual /* may be NULL */,
+                      int ldr, int M, int act, void* stream);
+int idxtts_linear_destroy(idxtts_linear* lin);
+/* Multi-head attention, head_dim 64, softmax(q k^T * scale + mask) v without materialising the scores.
+ * q/k/v/o are read in place: element (b, t, h, e) at base + b*batch_stride + t*token_stride + 64*h + e.
+ * causal: key <= query.  kstart/kend: optional device int32 [B], keys outside [kstart, kend) are masked
+ * (left padding of GPT prompts, model_v2.py:766-779; key padding of the DiT, diffusion_transformer.py:235-237). */
+int idxtts_attention_fwd(const float* q, const float* k, const float* v, float* o, long q_batch_stride, int q_token_stride,
+                         long kv_batch_stride, int kv_token_stride, long o_batch_stride, int o_token_stride, int B, int H,
+                         int Sq, int Sk, int causal, const int* kstart, const int* kend, float scale, void* stream);
+/* y = LayerNorm(x) * gamma + beta over the last dim (eps), rows of length d. */
+int idxtts_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, int M, int d, float eps, void* stream);
+
+/* ---- GPT stage (reference: UnifiedVoice.inference_speech model_v2.py:796-895, .forward 673-723) -----
+ * State-dict keys accepted by idxtts_ctx_load_tensor: gpt.h.{i}.{ln_1,ln_2}.{weight,bias},
+ * gpt.h.{i}.attn.{c_attn,c_proj}.{weight,bias}, gpt.h.{i}.mlp.{c_fc,c_proj}.{weight,bias}, gpt.ln_f.*, final_norm.*,
+ * mel_head.*, mel_embedding.weight, text_embedding.weight, mel_pos_embedding.emb.weight, text_pos_embedding.emb.weight,
+ * speed_emb.weight (UnifiedVoice.state_dict(), model_v2.py:381-443). */
+typedef struct idxtts_gpt_config {
+  int model_dim, heads, layers;          /* 1280, 20, 24 */
+  int number_mel_codes;                  /* 8194 */
+  int number_text_tokens;                /* 12000 (table has +1 rows) */
+  int start_mel_token, stop_mel_token;   /* 8192, 8193 */
+  int mel_pos_len, text_pos_len;         /* 1818, 602 */
+} idxtts_gpt_config;
+int idxtts_gpt_create(const idxtts_gpt_config* cfg, idxtts_ctx** out);
+/* Scratch for sequences of S tokens per row (prefill: P+1; latent pass: 34+L+2+M+2) and max_new_tokens of decode. */
+size_t idxtts_gpt_workspace_bytes(const idxtts_ctx* ctx, int B, int S, int max_new_tokens);
+/* out[r] = text_emb[text_ids[r]] + text_pos[text_pos_idx[r]] + mel_emb[mel_ids[r]] + mel_pos[mel_pos_idx[r]] + extra[extra_idx[r]],
+ * every term skipped where its index is < 0 (or its index array is NULL).  Index arrays are device int32 [rows].
+ * Builds the [pad|cond|text] prompt of prepare_gpt_inputs (model_v2.py:749-779) and the latent-pass input (704-716). */
+int idxtts_gpt_embed(idxtts_ctx* ctx, float* out, int rows, const int* text_ids, const int* text_pos_idx, const int* mel_ids,
+                     const int* mel_pos_idx, const float* extra, const int* extra_idx, void* stream);
+/* Greedy KV-cached generation = the accel_engine.generate plugin slot (model_v2.py:871-883) with the HF greedy
+ * semantics of the fallback path (do_sample=False, num_beams=1; RepetitionPenalty over the fake prefix + generated ids;
+ * finished rows emit stop_mel_token; stops when every row has stopped or at max_new_tokens).
+ * inputs_embeds: [B][P][d] device (the `tts_embeddings` argument); pad_left: HOST int32 [B] = number of left-pad rows
+ * (attention_mask zeros), may be NULL.  codes: device int64 [B][max_new_tokens]; *n_steps (host) = columns that are valid.
+ * logits_out: optional device [max_new_tokens][B][V] raw (pre-penalty) logits per step (disables graph replay). */
+int idxtts_gpt_generate(idxtts_ctx* ctx, const float* inputs_embeds, const int* pad_left, int B, int P, int max_new_tokens,
+                        float repetition_penalty, long long* codes, int* n_steps, float* logits_out, void* workspace,
+                        size_t workspace_bytes, int use_graph, void* stream);
+/* Latent pass: full causal forward over emb [B][S][d]; latent[b][i] = final_norm(ln_f(h[b][mel_start + i])), i < M. */
+int idxtts_gpt_latent(idxtts_ctx* ctx, const float* emb, int B, int S, int mel_start, int M, float* latent, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 /* ---- per-kernel timing for the benchmark's roofline report ------------------------------------------
  * When enabled, every kernel launch is bracketed by HIP events on its own stream and the library
  * accumulates, per kernel family, the launch count, elapsed milliseconds and the ALGORITHMIC flops /

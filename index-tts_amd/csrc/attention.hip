@@ -1,0 +1,194 @@
+// Flash-style multi-head attention (head_dim 64) on the gfx950 fp32 matrix core.
+//
+// Replaces the reference's attention call sites on the hot path:
+//   GPT-2 prefill / latent pass   causal + left-pad key mask   transformers_gpt2.py:196-234 (_attn),
+//                                                               487-575 (SDPA form), mask 1052-1058
+//   s2mel DiT                     non-causal + key-padding     gpt_fast/model.py:270-308 (SDPA with
+//                                                               attn_mask [B,1,T,T] from x_lens, diffusion_transformer.py:235-237)
+// q,k,v are read in place from a fused [B][S][*] projection buffer (token stride / head offset given),
+// the S x S score matrix is never materialised.
+//
+// CDNA4 mapping.  One workgroup = 4 waves = 128 query rows of one (batch, head); K/V tiles of 32 keys
+// are shared through LDS (register-staged double buffer, one barrier per tile).  Per wave and tile:
+//   S^T = K . Q^T   (32 keys x 32 queries, 32 x v_mfma_f32_32x32x2_f32 over d = 64)
+// is computed TRANSPOSED so that a query is a LANE: the online-softmax row statistics (max, sum) are
+// then per-lane scalars over the 16 accumulator registers plus ONE cross-half exchange
+// (__shfl_xor 32) instead of a 32-lane shuffle tree per row.  The probabilities stay in the
+// accumulator registers and feed the second product directly as its B operand
+//   O^T += V^T . P^T   (2 tiles of 32 d x 32 queries, k-order = accumulator row order)
+// so P never touches LDS.  Q fragments live in registers for the whole kernel (pre-scaled by 1/8).
+#include "attention.h"
+#include "prof.h"
+
+namespace idxtts {
+
+constexpr int KROW = 68;     // K tile row stride (floats): 64 + 4 pad -> conflict-free ds_read_b128 fragments
+constexpr float NEG_BIG = -1e30f;
+
+__global__ __launch_bounds__(256) void flash_attn_f32_kernel(const AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 32 * KROW + 2 * 32 * 64];
+  float (*Ks)[32 * KROW] = reinterpret_cast<float (*)[32 * KROW]>(smem);
+  float (*Vs)[32 * 64] = reinterpret_cast<float (*)[32 * 64]>(smem + 2 * 32 * KROW);
+
+  const int qblk = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int h = lane >> 5, j = lane & 31;
+  const int q0 = qblk * 128 + wave * 32;            // this wave's first query
+  const int qi = q0 + j;                            // this lane's query
+  const int kstart = p.kstart ? p.kstart[b] : 0;
+  const int kend = p.kend ? min(p.kend[b], p.Sk) : p.Sk;
+  // keys this block can see at all
+  int k_hi = kend;
+  if (p.causal) k_hi = min(k_hi, qblk * 128 + 128);
+  const int k_lo = kstart & ~31;
+  const int ntiles = k_hi > k_lo ? (k_hi - k_lo + 31) >> 5 : 0;
+
+  const float* qb = p.q + (size_t)b * p.q_bs + hd * 64;
+  const float* kb = p.k + (size_t)b * p.k_bs + hd * 64;
+  const float* vb = p.v + (size_t)b * p.v_bs + hd * 64;
+
+  // Q fragments: B operand of K.Q^T -> lane (j,h) holds Q[qi][8g + 4h + s], g = 0..7
+  f32x4 qf[8];
+  {
+    const bool ok = qi < p.Sq;
+    const float* qrow = qb + (size_t)(ok ? qi : 0) * p.q_ts;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(qrow + 8 * g + 4 * h);
+      qf[g] = v * p.scale;
+    }
+  }
+
+  f32x4 kr[2], vr[2];
+  auto load_kv = [&](int tile) {
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const int idx = tid + 256 * l;            // 512 float4 per 32x64 tile
+      const int row = idx >> 4, c4 = idx & 15;
+      const int key = k_lo + tile * 32 + row;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+      if (key < p.Sk) {
+        a = *reinterpret_cast<const f32x4*>(kb + (size_t)key * p.k_ts + c4 * 4);
+        c = *reinterpret_cast<const f32x4*>(vb + (size_t)key * p.v_ts + c4 * 4);
+      }
+      kr[l] = a;
+      vr[l] = c;
+    }
+  };
+  auto store_kv = [&](int buf) {
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const int idx = tid + 256 * l;
+      const int row = idx >> 4, c4 = idx & 15;
+      *reinterpret_cast<f32x4*>(&Ks[buf][row * KROW + c4 * 4]) = kr[l];
+      *reinterpret_cast<f32x4*>(&Vs[buf][row * 64 + c4 * 4]) = vr[l];
+    }
+  };
+
+  f32x16 o[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
+  float m_run = NEG_BIG, l_run = 0.0f;
+
+  if (ntiles > 0) {
+    load_kv(0);
+    store_kv(0);
+  }
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const bool has_next = tile + 1 < ntiles;
+    if (has_next) load_kv(tile + 1);
+    const float* kt = Ks[tile & 1];
+    const float* vt = Vs[tile & 1];
+    const int key0 = k_lo + tile * 32;
+    // wave-uniform skip: under the causal mask a tile entirely in this wave's future contributes nothing
+    const bool wave_active = !(p.causal && key0 > q0 + 31) && q0 < p.Sq;
+    if (wave_active) {
+      // ---- S^T = K . Q^T ----
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(kt + j * KROW + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[g][e], s, 0, 0, 0);
+      }
+      // ---- mask + online softmax (query = lane, keys = registers of both lane halves) ----
+      float mx = NEG_BIG;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool ok = key >= kstart && key < kend && (!p.causal || key <= qi);
+        s[r] = ok ? s[r] : NEG_BIG;
+        mx = fmaxf(mx, s[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = expf(m_run - m_new);       // m_run = NEG_BIG -> 0 (or 1 if still nothing seen: o,l are 0 anyway)
+      float psum = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = s[r] <= -1e29f ? 0.0f : expf(s[r] - m_new);
+        s[r] = pv;
+        psum += pv;
+      }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      // ---- O^T += V^T . P^T : k-step r uses key (r&3)+8(r>>2)+4h, exactly the row that register r of s holds ----
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int krow = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float* vrow = vt + krow * 64 + j;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[t * 32], s[r], o[t], 0, 0, 0);
+      }
+    }
+    if (has_next) store_kv((tile + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and store: O^T tiles (rows = d, cols = query) -> O[b][q][head*64 + d] through LDS ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv_l = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+  float* stage = smem + wave * (32 * 65);            // reuse the (now idle) K/V tiles as the transpose buffer
+  static_assert(4 * 32 * 65 <= 2 * 32 * KROW + 2 * 32 * 64, "output staging must fit in the K/V tiles");
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dd = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      stage[j * 65 + dd] = o[t][r] * inv_l;
+    }
+  __syncthreads();
+  float* ob = p.o + (size_t)b * p.o_bs + hd * 64;
+#pragma unroll
+  for (int it = 0; it < 32; ++it) {                  // one 256-byte output row per wave-instruction
+    const int qq = q0 + it;
+    if (qq < p.Sq) ob[(size_t)qq * p.o_ts + lane] = stage[it * 65 + lane];
+  }
+}
+
+int flash_attn_forward(const AttnArgs& a, hipStream_t stream) {
+  if (a.B == 0 || a.H == 0 || a.Sq == 0) return 0;
+  IDX_CHECK(a.q && a.k && a.v && a.o, "null pointer");
+  IDX_CHECK(a.head_dim == 64, "head_dim must be 64");
+  IDX_CHECK((a.q_ts & 3) == 0 && (a.k_ts & 3) == 0 && (a.v_ts & 3) == 0 && (a.q_bs & 3) == 0 && (a.k_bs & 3) == 0 && (a.v_bs & 3) == 0,
+            "q/k/v strides must be multiples of 4 floats");
+  dim3 grid(cdiv(a.Sq, 128), a.H, a.B);
+  const double flops = 4.0 * a.B * a.H * (double)a.Sq * a.Sk * 64 * (a.causal ? 0.5 : 1.0);
+  const double bytes = 4.0 * a.B * a.H * 64.0 * (2.0 * a.Sq + 2.0 * a.Sk);
+  ProfScope prof(PROF_FLASH_ATTN, stream, flops, bytes);
+  hipLaunchKernelGGL(flash_attn_f32_kernel, grid, dim3(256), 0, stream, a);
+  IDX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace idxtts

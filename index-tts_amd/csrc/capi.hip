@@ -6,6 +6,7 @@
 #include "bigvgan.h"
 #include "conv1d.h"
 #include "ctx.h"
+#include "gpt.h"
 
 namespace idxtts {
 
@@ -29,6 +30,11 @@ struct idxtts_conv1d {
   ConvWeights w;
   DeviceArena arena;
   int Cout = 0;
+};
+
+struct idxtts_linear {
+  LinearWeights w;
+  DeviceArena arena;
 };
 
 #define API_BEGIN try {
@@ -171,6 +177,113 @@ int idxtts_bigvgan_fwd(idxtts_ctx* ctx, const float* mel, float* wav, int B, int
   IDX_CHECK(m, "not a BigVGAN context");
   IDX_CHECK(B >= 0 && Tm >= 0, "negative shape");
   return m->forward(mel, wav, B, Tm, workspace, workspace_bytes, clamp, stage_idx, stage_out, static_cast<hipStream_t>(stream));
+  API_END
+}
+
+
+int idxtts_linear_create(const float* weight, const float* bias, int N, int K, int weight_is_kn, idxtts_linear** out) {
+  API_BEGIN
+  IDX_CHECK(weight && out && N > 0 && K > 0, "bad arguments");
+  std::unique_ptr<idxtts_linear> l(new idxtts_linear());
+  std::vector<float> hw, hb;
+  if (fetch(weight, (size_t)N * K, &hw)) return 1;
+  std::vector<float> packed(linear_packed_floats(N, K));
+  if (weight_is_kn) pack_linear_kn(packed.data(), hw.data(), K, N);
+  else pack_linear(packed.data(), hw.data(), N, K);
+  float* d = nullptr;
+  if (l->arena.upload(packed.data(), packed.size(), &d)) return 1;
+  l->w.wp = d; l->w.N = N; l->w.K = K;
+  if (bias) {
+    if (fetch(bias, N, &hb)) return 1;
+    if (l->arena.upload(hb.data(), hb.size(), &d)) return 1;
+    l->w.bias = d;
+  }
+  *out = l.release();
+  return 0;
+  API_END
+}
+
+int idxtts_linear_fwd(const idxtts_linear* lin, const float* x, int ldx, float* y, int ldy, const float* residual, int ldr, int M,
+                      int act, void* stream) {
+  API_BEGIN
+  IDX_CHECK(lin, "null handle");
+  GemmArgs a;
+  a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.res = residual; a.ldr = ldr; a.M = M; a.act = act;
+  return gemm_tn_forward(lin->w, a, static_cast<hipStream_t>(stream));
+  API_END
+}
+
+int idxtts_linear_destroy(idxtts_linear* lin) {
+  delete lin;
+  return 0;
+}
+
+int idxtts_attention_fwd(const float* q, const float* k, const float* v, float* o, long q_batch_stride, int q_token_stride,
+                         long kv_batch_stride, int kv_token_stride, long o_batch_stride, int o_token_stride, int B, int H,
+                         int Sq, int Sk, int causal, const int* kstart, const int* kend, float scale, void* stream) {
+  API_BEGIN
+  AttnArgs a;
+  a.q = q; a.k = k; a.v = v; a.o = o;
+  a.q_bs = q_batch_stride; a.k_bs = a.v_bs = kv_batch_stride; a.o_bs = o_batch_stride;
+  a.q_ts = q_token_stride; a.k_ts = a.v_ts = kv_token_stride; a.o_ts = o_token_stride;
+  a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.causal = causal; a.kstart = kstart; a.kend = kend; a.scale = scale;
+  return flash_attn_forward(a, static_cast<hipStream_t>(stream));
+  API_END
+}
+
+int idxtts_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, int M, int d, float eps, void* stream) {
+  API_BEGIN
+  RowsNormArgs n;
+  n.x_in = x; n.ld_in = d; n.y = y; n.ld_y = d; n.M = M; n.d = d; n.mode = NORM_LN; n.eps = eps; n.g1 = gamma; n.b1 = beta;
+  return rows_norm_forward(n, static_cast<hipStream_t>(stream));
+  API_END
+}
+
+int idxtts_gpt_create(const idxtts_gpt_config* cfg, idxtts_ctx** out) {
+  API_BEGIN
+  IDX_CHECK(cfg && out, "null pointer");
+  std::unique_ptr<idxtts_ctx> ctx(new idxtts_ctx());
+  ctx->model.reset(new GPTModel(*cfg));
+  *out = ctx.release();
+  return 0;
+  API_END
+}
+
+size_t idxtts_gpt_workspace_bytes(const idxtts_ctx* ctx, int B, int S, int max_new_tokens) {
+  if (!ctx || B <= 0 || S <= 0 || max_new_tokens < 0 || !ctx->finalized) return 0;
+  auto* m = dynamic_cast<const GPTModel*>(ctx->model.get());
+  return m ? m->workspace_bytes(B, S, max_new_tokens) : 0;
+}
+
+#define GPT_MODEL(ctx)                                        \
+  IDX_CHECK(ctx, "null ctx");                                 \
+  IDX_CHECK(ctx->finalized, "context not finalized");         \
+  auto* m = dynamic_cast<GPTModel*>(ctx->model.get());        \
+  IDX_CHECK(m, "not a GPT context")
+
+int idxtts_gpt_embed(idxtts_ctx* ctx, float* out, int rows, const int* text_ids, const int* text_pos_idx, const int* mel_ids,
+                     const int* mel_pos_idx, const float* extra, const int* extra_idx, void* stream) {
+  API_BEGIN
+  GPT_MODEL(ctx);
+  return m->embed(out, rows, text_ids, text_pos_idx, mel_ids, mel_pos_idx, extra, extra_idx, static_cast<hipStream_t>(stream));
+  API_END
+}
+
+int idxtts_gpt_generate(idxtts_ctx* ctx, const float* inputs_embeds, const int* pad_left, int B, int P, int max_new_tokens,
+                        float repetition_penalty, long long* codes, int* n_steps, float* logits_out, void* workspace,
+                        size_t workspace_bytes, int use_graph, void* stream) {
+  API_BEGIN
+  GPT_MODEL(ctx);
+  return m->generate(inputs_embeds, pad_left, B, P, max_new_tokens, repetition_penalty, codes, n_steps, logits_out, workspace,
+                     workspace_bytes, use_graph, static_cast<hipStream_t>(stream));
+  API_END
+}
+
+int idxtts_gpt_latent(idxtts_ctx* ctx, const float* emb, int B, int S, int mel_start, int M, float* latent, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  API_BEGIN
+  GPT_MODEL(ctx);
+  return m->latent(emb, B, S, mel_start, M, latent, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
   API_END
 }
 

@@ -1,0 +1,51 @@
+#pragma once
+#include "common.h"
+
+namespace idxtts {
+
+struct DecodeState {   // device-resident per-generation scalars (replay-friendly)
+  int pos;       // KV index of the token being processed (= keys already in the cache)
+  int mel_pos;   // row of mel_pos_embedding for that token (reference quirk: 0, 2, 3, 4, ... model_v2.py:175-177)
+  int step;      // column of `codes` the sampler writes
+  int pad;
+};
+
+struct DecodeAttnArgs {
+  const float* qkv_part = nullptr; int parts = 0; int part_rows = 0;   // [parts][part_rows][3d] c_attn split-K slab
+  const float* qkv_bias = nullptr;                                      // [3d]
+  float* kcache = nullptr; float* vcache = nullptr;                     // this layer: [B][H][16][Smax][4] / [B][H][Smax][64]
+  float* out = nullptr;                                                 // [B][d]
+  const int* kstart = nullptr;                                          // [B] first valid key (left pad), or null
+  const DecodeState* st = nullptr;
+  int B = 0, H = 0, Smax = 0, d = 0;
+  float scale = 0.125f;
+};
+int decode_attn_forward(const DecodeAttnArgs& a, hipStream_t stream);
+
+struct SampleArgs {
+  const float* part = nullptr; int parts = 0; int part_rows = 0;   // [parts][part_rows][V] lm_head split-K slab
+  const float* bias = nullptr;                                     // [V]
+  float* logits_out = nullptr;                                     // optional [B][V] raw logits of this step
+  unsigned char* seen = nullptr;                                   // [B][V] ids present in input_ids
+  int* finished = nullptr;                                         // [B]
+  long long* codes = nullptr; int codes_ld = 0;                    // [B][codes_ld]
+  int* cur_tok = nullptr;                                          // [B]
+  const DecodeState* st = nullptr;
+  int B = 0, V = 0, stop_token = 0;
+  float penalty = 1.0f;
+};
+int sample_greedy_forward(const SampleArgs& a, hipStream_t stream);
+
+int advance_state(DecodeState* st, hipStream_t stream);
+int kv_store_prefill(const float* qkv, float* kcache, float* vcache, int B, int H, int S, int Smax, int d, hipStream_t stream);
+constexpr int GATHER_MAX_TABLES = 5;
+struct GatherArgs {
+  float* out = nullptr; int ld_out = 0; int d = 0;
+  const float* table[GATHER_MAX_TABLES] = {};   // [n_t][d]
+  const int* idx[GATHER_MAX_TABLES] = {};       // [rows], -1 = skip
+};
+int gather_sum_rows(const GatherArgs& a, int rows, hipStream_t stream);
+int embed_step(float* x, int B, int d, const float* mel_emb, const float* mel_pos, const int* cur_tok, const DecodeState* st,
+               hipStream_t stream);
+
+}  // namespace idxtts

@@ -1,0 +1,34 @@
+// Token-major linear layers on the fp32 matrix core:  Y[M][N] = epi(X[M][K] * W^T + bias).
+#pragma once
+#include "common.h"
+
+namespace idxtts {
+
+enum GemmAct { ACT_NONE = 0, ACT_GELU_NEW = 1, ACT_SILU = 2, ACT_SWIGLU = 3, ACT_MISH = 4 };
+
+struct LinearWeights {      // device-resident, packed for the MFMA B operand
+  const float* wp = nullptr;   // [ceil(N/32)][ceil(K/16)][g2][h2][j32][4]
+  const float* bias = nullptr; // [N] (for SWIGLU: [N] in packed row order) or null
+  int N = 0, K = 0;
+};
+
+static inline size_t linear_packed_floats(int N, int K) { return (size_t)cdiv(N, 32) * cdiv(K, 16) * 512; }
+
+// w: [N][K] row-major (torch nn.Linear layout).  Same sub-tile format as the conv weights with one tap.
+void pack_linear(float* dst, const float* w, int N, int K);
+// HF Conv1D layout [K][N] (y = x @ W + b).
+void pack_linear_kn(float* dst, const float* w_kn, int K, int N);
+
+struct GemmArgs {
+  const float* x = nullptr; int ldx = 0;      // [M][K], row stride ldx floats
+  float* y = nullptr; int ldy = 0;            // [M][N] (SWIGLU: [M][N/2])
+  const float* res = nullptr; int ldr = 0;    // optional residual added after the activation
+  // optional per-row-group modulation of the OUTPUT (adaLN etc. are handled by the norm kernels, not here)
+  int M = 0;
+  int act = ACT_NONE;
+  float out_scale = 1.0f;
+};
+
+int gemm_tn_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t stream);
+
+}  // namespace idxtts

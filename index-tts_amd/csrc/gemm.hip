@@ -1,0 +1,234 @@
+// Token-major GEMM on the gfx950 fp32 matrix core: Y[M][N] = epi(X[M][K] * W^T + bias).
+//
+// Replaces the nn.Linear / HF Conv1D call sites of the hot path:
+//   GPT-2 block c_attn / c_proj / c_fc / mlp.c_proj  (indextts/gpt/transformers_gpt2.py:304-355, 578-592)
+//   DiT wqkv / wo / w1,w3 / w2 / skip_in_linear      (indextts/s2mel/modules/gpt_fast/model.py:233-234, 270-308, 311-319)
+//   DiT cond_projection, cond_x_merge_linear, skip_linear, conv1, res_projection, final_layer, conv2
+//                                                    (indextts/s2mel/modules/diffusion_transformer.py:213-252)
+//   gpt_layer / content_in_proj                      (commons.py:413, length_regulator.py:88)
+//
+// 128x128 output tile per 256-thread workgroup (2x2 waves, each 2x2 tiles of v_mfma_f32_32x32x2_f32),
+// K stepped 32 at a time through an LDS double buffer with register staging (loads issued before the
+// 64-MFMA block, LDS writes after it, one barrier per step).  Both operands are K-contiguous in HBM;
+// in LDS both are kept in the MFMA fragment order [g][h][row][4] so every fragment read is one
+// ds_read_b128 of 64 x 16 contiguous bytes (conflict-free).  The activation tile gets there through a
+// transposing register->LDS write; its 512-byte sub-blocks are padded to 528 B so the 8 lanes that hold
+// one 128-byte row segment hit 8 different bank groups.  W is packed once at context creation.
+// XCD-aware tile map: XCD x owns the m-tiles == x (mod 8) and walks them n-block-major, so the 32 CUs of
+// an XCD share one weight slice in their L2 while streaming different activation rows.
+#include <cmath>
+
+#include "gemm.h"
+#include "prof.h"
+
+namespace idxtts {
+
+void pack_linear(float* dst, const float* w, int N, int K) {
+  const int NT = cdiv(N, 32), KC = cdiv(K, 16);
+  for (int nt = 0; nt < NT; ++nt)
+    for (int c = 0; c < KC; ++c) {
+      float* sub = dst + ((size_t)nt * KC + c) * 512;
+      for (int g = 0; g < 2; ++g)
+        for (int h = 0; h < 2; ++h)
+          for (int j = 0; j < 32; ++j)
+            for (int e = 0; e < 4; ++e) {
+              const int n = nt * 32 + j, k = c * 16 + 8 * g + 4 * h + e;
+              sub[((g * 2 + h) * 32 + j) * 4 + e] = (n < N && k < K) ? w[(size_t)n * K + k] : 0.0f;
+            }
+    }
+}
+
+void pack_linear_kn(float* dst, const float* w_kn, int K, int N) {
+  const int NT = cdiv(N, 32), KC = cdiv(K, 16);
+  for (int nt = 0; nt < NT; ++nt)
+    for (int c = 0; c < KC; ++c) {
+      float* sub = dst + ((size_t)nt * KC + c) * 512;
+      for (int g = 0; g < 2; ++g)
+        for (int h = 0; h < 2; ++h)
+          for (int j = 0; j < 32; ++j)
+            for (int e = 0; e < 4; ++e) {
+              const int n = nt * 32 + j, k = c * 16 + 8 * g + 4 * h + e;
+              sub[((g * 2 + h) * 32 + j) * 4 + e] = (n < N && k < K) ? w_kn[(size_t)k * N + n] : 0.0f;
+            }
+    }
+}
+
+struct GemmKP {
+  const float* x; const float* wp; const float* bias; const float* res; float* y;
+  int M, N, K, ldx, ldy, ldr;
+  int kc16;        // 16-wide K chunks in the packed weights
+  int mtiles, mt8; // 128-row tiles, ceil(mtiles/8)
+  int act;
+  float out_scale;
+};
+
+constexpr int XBLK = 132;   // floats per padded [32 rows][4] sub-block (528 B)
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == ACT_GELU_NEW) {
+    const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+    return 0.5f * v * (1.0f + tanhf(u));
+  }
+  if (act == ACT_SILU) return v / (1.0f + expf(-v));
+  if (act == ACT_MISH) {   // x * tanh(softplus(x)), softplus threshold 20 as torch
+    const float sp = v > 20.0f ? v : log1pf(expf(v));
+    return v * tanhf(sp);
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmKP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float (*Xs)[4 * 2 * 4 * XBLK] = reinterpret_cast<float (*)[4 * 2 * 4 * XBLK]>(smem);
+  float (*Ws)[4 * 2 * 512] = reinterpret_cast<float (*)[4 * 2 * 512]>(smem + 2 * 4 * 2 * 4 * XBLK);
+
+  const int L = blockIdx.x, xcd = L & 7, q = L >> 3;
+  const int bn = q / p.mt8;
+  const int bm = (q - bn * p.mt8) * 8 + xcd;
+  if (bm >= p.mtiles) return;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int h = lane >> 5, j = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  f32x4 xr[4], wr[4];
+  auto load_tiles = [&](int kstep) {
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const int idx = tid + 256 * l;
+      // activations: 8 lanes per 128-byte row segment
+      const int row = idx >> 3, q8 = idx & 7;
+      const int m = bm * 128 + row, k = kstep * 32 + q8 * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < p.M && k < p.K) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.ldx + k);
+      xr[l] = v;
+      // weights: 4 KiB contiguous per 32-column tile (two 16-wide chunks)
+      const int nt = idx >> 8, off = idx & 255;
+      const int ntg = bn * 4 + nt, c16 = kstep * 2 + (off >> 7);
+      f32x4 u = {0.f, 0.f, 0.f, 0.f};
+      if (ntg * 32 < p.N && c16 < p.kc16)
+        u = *reinterpret_cast<const f32x4*>(p.wp + ((size_t)ntg * p.kc16 + c16) * 512 + (off & 127) * 4);
+      wr[l] = u;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const int idx = tid + 256 * l;
+      const int row = idx >> 3, q8 = idx & 7;
+      const int mt = row >> 5, i = row & 31, c = q8 >> 2, gh = q8 & 3;
+      *reinterpret_cast<f32x4*>(&Xs[buf][((mt * 2 + c) * 4 + gh) * XBLK + i * 4]) = xr[l];
+      const int nt = idx >> 8, off = idx & 255;
+      *reinterpret_cast<f32x4*>(&Ws[buf][nt * 1024 + off * 4]) = wr[l];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  const int ksteps = (p.kc16 + 1) >> 1;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const bool has_next = ks + 1 < ksteps;
+    if (has_next) load_tiles(ks + 1);
+    const float* xb = Xs[ks & 1];
+    const float* wb = Ws[ks & 1];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        f32x4 a[2], b[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          a[t] = *reinterpret_cast<const f32x4*>(xb + (((wm * 2 + t) * 2 + c) * 4 + (g * 2 + h)) * XBLK + j * 4);
+          b[t] = *reinterpret_cast<const f32x4*>(wb + (wn * 2 + t) * 1024 + c * 512 + (g * 64 + lane) * 4);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
+      }
+    if (has_next) store_tiles((ks + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  if (p.act == ACT_SWIGLU) {
+    // packed rows alternate [32 of w1 | 32 of w3]: acc[.][0] is the gate, acc[.][1] the linear branch
+    const int n0 = bn * 128 + wn * 64 + j;            // packed column of the gate
+    const int no = bn * 64 + wn * 32 + j;             // output column
+    const bool ok = (bn * 128 + wn * 64) < p.N;       // N % 64 == 0: a wave's 64 packed columns are all in or all out
+    const float b0 = (p.bias && ok) ? p.bias[n0] : 0.0f, b1 = (p.bias && ok) ? p.bias[n0 + 32] : 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = bm * 128 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= p.M || !ok) continue;
+        const float gte = acc[mt][0][r] + b0, lin = acc[mt][1][r] + b1;
+        float v = (gte / (1.0f + expf(-gte))) * lin * p.out_scale;
+        if (p.res) v += p.res[(size_t)m * p.ldr + no];
+        p.y[(size_t)m * p.ldy + no] = v;
+      }
+    return;
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = bn * 128 + wn * 64 + nt * 32 + j;
+    if (n >= p.N) continue;
+    const float bias = p.bias ? p.bias[n] : 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = bm * 128 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        float v = act_apply(acc[mt][nt][r] + bias, p.act) * p.out_scale;
+        if (p.res) v += p.res[(size_t)m * p.ldr + n];
+        p.y[(size_t)m * p.ldy + n] = v;
+      }
+  }
+}
+
+int gemm_tn_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t stream) {
+  IDX_CHECK(w.wp && a.x && a.y, "null pointer");
+  if (a.M == 0) return 0;
+  IDX_CHECK(a.M > 0 && w.N > 0 && w.K > 0, "bad shape");
+  IDX_CHECK((w.K & 3) == 0 && (a.ldx & 3) == 0, "K and ldx must be multiples of 4 (16-byte row segments)");
+  IDX_CHECK((reinterpret_cast<uintptr_t>(a.x) & 15) == 0, "x must be 16-byte aligned");
+  if (a.act == ACT_SWIGLU) IDX_CHECK((w.N & 63) == 0, "SWIGLU needs N (= 2*hidden) to be a multiple of 64");
+  GemmKP p;
+  p.x = a.x; p.wp = w.wp; p.bias = w.bias; p.res = a.res; p.y = a.y;
+  p.M = a.M; p.N = w.N; p.K = w.K; p.ldx = a.ldx; p.ldy = a.ldy; p.ldr = a.ldr;
+  p.kc16 = cdiv(w.K, 16);
+  p.mtiles = cdiv(a.M, 128);
+  p.mt8 = cdiv(p.mtiles, 8);
+  p.act = a.act; p.out_scale = a.out_scale;
+  const int nblocks = cdiv(w.N, 128);
+  const int64_t grid = (int64_t)8 * nblocks * p.mt8;
+  IDX_CHECK(grid < (1ll << 31), "grid size");
+  const double flops = 2.0 * a.M * (double)w.N * w.K;
+  const double bytes = 4.0 * ((double)a.M * w.K + (double)w.N * w.K + (double)a.M * w.N * (a.res ? 2.0 : 1.0));
+  ProfScope prof(PROF_GEMM_TN, stream, flops, bytes);
+  constexpr size_t lds = (size_t)(2 * 4 * 2 * 4 * XBLK + 2 * 4 * 2 * 512) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)grid), dim3(256), lds, stream, p);
+  IDX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace idxtts

@@ -1,0 +1,54 @@
+#pragma once
+#include "../../include/idxtts.h"
+#include "attention.h"
+#include "ctx.h"
+#include "decode.h"
+#include "gemm.h"
+#include "gemv16.h"
+#include "norm.h"
+#include "prof.h"
+
+namespace idxtts {
+
+struct GPTLayer {
+  const float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+  LinearWeights attn_l, proj_l, fc_l, fc2_l;     // MFMA-32x32 packed (prefill / latent pass)
+  Gemv16Weights attn_g, proj_g, fc_g, fc2_g;     // stream-order packed (decode)
+};
+
+struct GPTModel : ModelBase {
+  idxtts_gpt_config cfg;
+  std::vector<GPTLayer> layers;
+  const float *lnf_g = nullptr, *lnf_b = nullptr, *fn_g = nullptr, *fn_b = nullptr;
+  Gemv16Weights head_g;
+  const float* head_b = nullptr;
+  const float *mel_emb = nullptr, *text_emb = nullptr, *mel_pos = nullptr, *text_pos = nullptr;
+  int ks_attn = 1, ks_proj = 1, ks_fc = 1, ks_fc2 = 1, ks_head = 1;
+
+  struct Buffers {
+    float *x, *h, *qkv, *att, *ff;            // [B*S][..] prefill / latent activations
+    float *kcache, *vcache; int Smax;         // [L][B][H][Smax][64] each
+    float *xd, *hd, *attd;                    // [B][d] decode residual / normed / attention output
+    float *slab_a, *slab_b;                   // split-K partial slabs
+    unsigned char* seen; int *finished, *cur_tok, *kstart;
+    DecodeState* state;
+    size_t bytes;
+  };
+
+  explicit GPTModel(const idxtts_gpt_config& c);
+  bool accepts(const std::string& name) const override;
+  int finalize(std::map<std::string, HostTensor>& t, DeviceArena& arena) override;
+  Buffers carve(void* ws, int B, int S, int max_new) const;
+  size_t workspace_bytes(int B, int S, int max_new) const;
+  int layer_full(int li, const Buffers& w, int B, int S, const int* kstart, bool store_kv, hipStream_t st);
+  int head_and_sample(const Buffers& w, int B, const RowsNormArgs& norm_in, float penalty, long long* codes, int codes_ld,
+                      float* logits_out, hipStream_t st);
+  int decode_step(const Buffers& w, int B, float penalty, long long* codes, int codes_ld, float* logits_base, hipStream_t st);
+  int generate(const float* inputs_embeds, const int* pad_left_host, int B, int P, int max_new, float penalty, long long* codes,
+               int* n_steps_out, float* logits_out, void* ws, size_t ws_bytes, int use_graph, hipStream_t st);
+  int latent(const float* emb, int B, int S, int mel_start, int M, float* latent_out, void* ws, size_t ws_bytes, hipStream_t st);
+  int embed(float* out, int rows, const int* text_ids, const int* text_pos_idx, const int* mel_ids, const int* mel_pos_idx,
+            const float* extra, const int* extra_idx, hipStream_t st);
+};
+
+}  // namespace idxtts

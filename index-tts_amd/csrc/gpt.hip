@@ -1,0 +1,386 @@
+// IndexTTS-2 GPT stage on MI355X: prefill, KV-cached greedy decode and the latent pass.
+//
+// Reference: UnifiedVoice.inference_speech model_v2.py:796-895 (decode through GPT2InferenceModel.forward
+// 131-225 + GenerationMixin._sample, or the accel_engine.generate plugin slot 871-883), and
+// UnifiedVoice.forward 673-723 (latent pass).  The 24 GPT-2 blocks are third-party HF code
+// (transformers_gpt2.py:615-674 is the in-tree spec).
+//
+// Two weight copies are kept on purpose (288 GB HBM): an MFMA-32x32 packed copy for the GEMM-shaped
+// passes (prefill, latent: M = B*S rows) and a B-fragment stream-order copy for the M<=64 decode GEMVs.
+//
+// Decode step = 7 launches per layer (rows_norm[LN1 + residual + split-K combine] -> gemv16 c_attn ->
+// decode_attn -> gemv16 c_proj -> rows_norm[LN2 ...] -> gemv16 c_fc -> gemv16 mlp.c_proj with fused
+// gelu_new on its input slab), + embedding, head and sampler; every per-step scalar is device-resident so the
+// whole step is captured once into a hipGraph and replayed per token (launch-bound otherwise).
+#include <cstring>
+
+#include "gpt.h"
+
+namespace idxtts {
+
+GPTModel::GPTModel(const idxtts_gpt_config& c) : cfg(c) {}
+
+bool GPTModel::accepts(const std::string& name) const {
+  static const char* prefixes[] = {"gpt.h.", "gpt.ln_f.", "final_norm.", "mel_head.", "mel_embedding.", "text_embedding.",
+                                   "mel_pos_embedding.", "text_pos_embedding.", "speed_emb."};
+  for (const char* p : prefixes)
+    if (name.rfind(p, 0) == 0) return true;
+  return false;
+}
+
+static int need(std::map<std::string, HostTensor>& t, const std::string& key, std::vector<int64_t> shape, HostTensor** out) {
+  auto it = t.find(key);
+  if (it == t.end()) IDX_FAIL("missing tensor '" + key + "'");
+  if (it->second.shape != shape) IDX_FAIL("tensor '" + key + "' has the wrong shape");
+  *out = &it->second;
+  return 0;
+}
+
+static int upload(std::map<std::string, HostTensor>& t, DeviceArena& arena, const std::string& key, std::vector<int64_t> shape,
+                  const float** out) {
+  HostTensor* v = nullptr;
+  if (need(t, key, shape, &v)) return 1;
+  float* d = nullptr;
+  if (arena.upload(v->data.data(), v->data.size(), &d)) return 1;
+  *out = d;
+  return 0;
+}
+
+// HF Conv1D weight [K][N] -> both packed forms
+static int make_proj(std::map<std::string, HostTensor>& t, DeviceArena& arena, const std::string& prefix, int K, int N,
+                     LinearWeights* lw, Gemv16Weights* gw) {
+  HostTensor* w = nullptr;
+  if (need(t, prefix + ".weight", {K, N}, &w)) return 1;
+  std::vector<float> buf(linear_packed_floats(N, K));
+  pack_linear_kn(buf.data(), w->data.data(), K, N);
+  float* d = nullptr;
+  if (arena.upload(buf.data(), buf.size(), &d)) return 1;
+  lw->wp = d; lw->N = N; lw->K = K;
+  if (upload(t, arena, prefix + ".bias", {N}, &lw->bias)) return 1;
+  buf.assign(gemv16_packed_floats(N, K), 0.0f);
+  pack_gemv16_kn(buf.data(), w->data.data(), K, N);
+  if (arena.upload(buf.data(), buf.size(), &d)) return 1;
+  gw->wp = d; gw->N = N; gw->K = K;
+  return 0;
+}
+
+int GPTModel::finalize(std::map<std::string, HostTensor>& t, DeviceArena& arena) {
+  const int d = cfg.model_dim, f = 4 * d;
+  IDX_CHECK(d == cfg.heads * 64, "head_dim must be 64");
+  IDX_CHECK(cfg.layers > 0 && (d & 15) == 0, "config");
+  layers.resize(cfg.layers);
+  for (int i = 0; i < cfg.layers; ++i) {
+    GPTLayer& L = layers[i];
+    const std::string p = "gpt.h." + std::to_string(i);
+    if (upload(t, arena, p + ".ln_1.weight", {d}, &L.ln1_g) || upload(t, arena, p + ".ln_1.bias", {d}, &L.ln1_b)) return 1;
+    if (upload(t, arena, p + ".ln_2.weight", {d}, &L.ln2_g) || upload(t, arena, p + ".ln_2.bias", {d}, &L.ln2_b)) return 1;
+    if (make_proj(t, arena, p + ".attn.c_attn", d, 3 * d, &L.attn_l, &L.attn_g)) return 1;
+    if (make_proj(t, arena, p + ".attn.c_proj", d, d, &L.proj_l, &L.proj_g)) return 1;
+    if (make_proj(t, arena, p + ".mlp.c_fc", d, f, &L.fc_l, &L.fc_g)) return 1;
+    if (make_proj(t, arena, p + ".mlp.c_proj", f, d, &L.fc2_l, &L.fc2_g)) return 1;
+  }
+  if (upload(t, arena, "gpt.ln_f.weight", {d}, &lnf_g) || upload(t, arena, "gpt.ln_f.bias", {d}, &lnf_b)) return 1;
+  if (upload(t, arena, "final_norm.weight", {d}, &fn_g) || upload(t, arena, "final_norm.bias", {d}, &fn_b)) return 1;
+  const int V = cfg.number_mel_codes;
+  HostTensor* hw = nullptr;
+  if (need(t, "mel_head.weight", {V, d}, &hw)) return 1;
+  std::vector<float> buf(gemv16_packed_floats(V, d));
+  pack_gemv16_nk(buf.data(), hw->data.data(), V, d);
+  float* dp = nullptr;
+  if (arena.upload(buf.data(), buf.size(), &dp)) return 1;
+  head_g.wp = dp; head_g.N = V; head_g.K = d;
+  if (upload(t, arena, "mel_head.bias", {V}, &head_b)) return 1;
+  if (upload(t, arena, "mel_embedding.weight", {V, d}, &mel_emb)) return 1;
+  if (upload(t, arena, "text_embedding.weight", {cfg.number_text_tokens + 1, d}, &text_emb)) return 1;
+  if (upload(t, arena, "mel_pos_embedding.emb.weight", {cfg.mel_pos_len, d}, &mel_pos)) return 1;
+  if (upload(t, arena, "text_pos_embedding.emb.weight", {cfg.text_pos_len, d}, &text_pos)) return 1;
+  ks_attn = gemv16_plan_ksplit(3 * d, d);
+  ks_proj = gemv16_plan_ksplit(d, d);
+  ks_fc = gemv16_plan_ksplit(f, d);
+  ks_fc2 = gemv16_plan_ksplit(d, f);
+  ks_head = gemv16_plan_ksplit(V, d);
+  return 0;
+}
+
+// ---- workspace carving ----
+struct Carver {
+  char* base; size_t off = 0;
+  explicit Carver(void* b) : base(static_cast<char*>(b)) {}
+  template <typename T> T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+GPTModel::Buffers GPTModel::carve(void* ws, int B, int S, int max_new) const {
+  const int d = cfg.model_dim, V = cfg.number_mel_codes, L = cfg.layers;
+  Buffers b;
+  Carver c(ws);
+  const size_t rows = (size_t)B * S;
+  b.x = c.take<float>(rows * d);
+  b.h = c.take<float>(rows * d);
+  b.qkv = c.take<float>(rows * 3 * d);
+  b.att = c.take<float>(rows * d);
+  b.ff = c.take<float>(rows * 4 * d);
+  b.Smax = max_new > 0 ? ((S + max_new + 3) & ~3) : 0;
+  const size_t cache = (size_t)L * B * cfg.heads * b.Smax * 64;
+  b.kcache = c.take<float>(cache);
+  b.vcache = c.take<float>(cache);
+  b.xd = c.take<float>((size_t)B * d);
+  b.hd = c.take<float>((size_t)B * d);
+  b.attd = c.take<float>((size_t)B * d);
+  size_t slab = 0;
+  slab = std::max(slab, (size_t)ks_attn * B * 3 * d);
+  slab = std::max(slab, (size_t)ks_proj * B * d);
+  slab = std::max(slab, (size_t)ks_fc * B * 4 * d);
+  slab = std::max(slab, (size_t)ks_fc2 * B * d);
+  slab = std::max(slab, (size_t)ks_head * B * V);
+  b.slab_a = c.take<float>(slab);
+  b.slab_b = c.take<float>(slab);
+  b.seen = c.take<unsigned char>((size_t)B * V);
+  b.finished = c.take<int>(B);
+  b.cur_tok = c.take<int>(B);
+  b.kstart = c.take<int>(B);
+  b.state = c.take<DecodeState>(1);
+  b.bytes = (c.off + 255) & ~(size_t)255;
+  return b;
+}
+
+size_t GPTModel::workspace_bytes(int B, int S, int max_new) const { return carve(nullptr, B, S, max_new).bytes; }
+
+// one transformer layer over M = B*S token rows (prefill / latent pass)
+int GPTModel::layer_full(int li, const Buffers& w, int B, int S, const int* kstart, bool store_kv, hipStream_t st) {
+  const GPTLayer& L = layers[li];
+  const int d = cfg.model_dim, M = B * S;
+  RowsNormArgs n1;
+  n1.x_in = w.x; n1.ld_in = d; n1.y = w.h; n1.ld_y = d; n1.M = M; n1.d = d; n1.mode = NORM_LN; n1.g1 = L.ln1_g; n1.b1 = L.ln1_b;
+  if (rows_norm_forward(n1, st)) return 1;
+  GemmArgs g;
+  g.x = w.h; g.ldx = d; g.y = w.qkv; g.ldy = 3 * d; g.M = M;
+  if (gemm_tn_forward(L.attn_l, g, st)) return 1;
+  if (store_kv) {
+    const size_t per_layer = (size_t)B * cfg.heads * w.Smax * 64;
+    if (kv_store_prefill(w.qkv, w.kcache + li * per_layer, w.vcache + li * per_layer, B, cfg.heads, S, w.Smax, d, st)) return 1;
+  }
+  AttnArgs a;
+  a.q = w.qkv; a.k = w.qkv + d; a.v = w.qkv + 2 * d; a.o = w.att;
+  a.q_bs = a.k_bs = a.v_bs = (long)S * 3 * d; a.o_bs = (long)S * d;
+  a.q_ts = a.k_ts = a.v_ts = 3 * d; a.o_ts = d;
+  a.B = B; a.H = cfg.heads; a.Sq = S; a.Sk = S; a.causal = 1; a.kstart = kstart; a.scale = 0.125f;
+  if (flash_attn_forward(a, st)) return 1;
+  GemmArgs p;
+  p.x = w.att; p.ldx = d; p.y = w.x; p.ldy = d; p.res = w.x; p.ldr = d; p.M = M;
+  if (gemm_tn_forward(L.proj_l, p, st)) return 1;
+  RowsNormArgs n2 = n1;
+  n2.g1 = L.ln2_g; n2.b1 = L.ln2_b;
+  if (rows_norm_forward(n2, st)) return 1;
+  GemmArgs f1;
+  f1.x = w.h; f1.ldx = d; f1.y = w.ff; f1.ldy = 4 * d; f1.M = M; f1.act = ACT_GELU_NEW;
+  if (gemm_tn_forward(L.fc_l, f1, st)) return 1;
+  GemmArgs f2;
+  f2.x = w.ff; f2.ldx = 4 * d; f2.y = w.x; f2.ldy = d; f2.res = w.x; f2.ldr = d; f2.M = M;
+  if (gemm_tn_forward(L.fc2_l, f2, st)) return 1;
+  return 0;
+}
+
+// head on B rows: ln_f -> final_norm -> mel_head (split-K slab) -> greedy sampler
+int GPTModel::head_and_sample(const Buffers& w, int B, const RowsNormArgs& norm_in, float penalty, long long* codes, int codes_ld,
+                              float* logits_out, hipStream_t st) {
+  const int d = cfg.model_dim, V = cfg.number_mel_codes;
+  RowsNormArgs n = norm_in;
+  n.y = w.hd; n.ld_y = d; n.M = B; n.d = d; n.mode = NORM_LN_LN;
+  n.g1 = lnf_g; n.b1 = lnf_b; n.g2 = fn_g; n.b2 = fn_b;
+  if (rows_norm_forward(n, st)) return 1;
+  Gemv16Args hv;
+  hv.x = w.hd; hv.ldx = d; hv.ypart = w.slab_b; hv.rows = B; hv.ksplit = ks_head;
+  if (gemv16_forward(head_g, hv, st)) return 1;
+  SampleArgs s;
+  s.part = w.slab_b; s.parts = ks_head; s.part_rows = B; s.bias = head_b; s.logits_out = logits_out;
+  s.seen = w.seen; s.finished = w.finished; s.codes = codes; s.codes_ld = codes_ld; s.cur_tok = w.cur_tok;
+  s.st = w.state; s.B = B; s.V = V; s.stop_token = cfg.stop_mel_token; s.penalty = penalty;
+  return sample_greedy_forward(s, st);
+}
+
+// one autoregressive step for all B rows (replayable: no host-dependent arguments)
+int GPTModel::decode_step(const Buffers& w, int B, float penalty, long long* codes, int codes_ld, float* logits_base,
+                          hipStream_t st) {
+  const int d = cfg.model_dim, f = 4 * d;
+  const size_t per_layer = (size_t)B * cfg.heads * w.Smax * 64;
+  if (embed_step(w.xd, B, d, mel_emb, mel_pos, w.cur_tok, w.state, st)) return 1;
+  for (int li = 0; li < cfg.layers; ++li) {
+    const GPTLayer& L = layers[li];
+    // LN1; for li > 0 this also folds the previous layer's mlp.c_proj: x += bias + sum_s slab
+    RowsNormArgs n1;
+    n1.x_in = w.xd; n1.ld_in = d; n1.y = w.hd; n1.ld_y = d; n1.M = B; n1.d = d; n1.mode = NORM_LN; n1.g1 = L.ln1_g; n1.b1 = L.ln1_b;
+    if (li > 0) {
+      n1.add_bias = layers[li - 1].fc2_l.bias; n1.partials = w.slab_b; n1.num_partials = ks_fc2; n1.partial_rows = B; n1.ld_partial = d;
+      n1.x_out = w.xd; n1.ld_out = d;
+    }
+    if (rows_norm_forward(n1, st)) return 1;
+    Gemv16Args qa;
+    qa.x = w.hd; qa.ldx = d; qa.ypart = w.slab_a; qa.rows = B; qa.ksplit = ks_attn;
+    if (gemv16_forward(L.attn_g, qa, st)) return 1;
+    DecodeAttnArgs da;
+    da.qkv_part = w.slab_a; da.parts = ks_attn; da.part_rows = B; da.qkv_bias = L.attn_l.bias;
+    da.kcache = w.kcache + li * per_layer; da.vcache = w.vcache + li * per_layer; da.out = w.attd; da.kstart = w.kstart;
+    da.st = w.state; da.B = B; da.H = cfg.heads; da.Smax = w.Smax; da.d = d; da.scale = 0.125f;
+    if (decode_attn_forward(da, st)) return 1;
+    Gemv16Args pa;
+    pa.x = w.attd; pa.ldx = d; pa.ypart = w.slab_b; pa.rows = B; pa.ksplit = ks_proj;
+    if (gemv16_forward(L.proj_g, pa, st)) return 1;
+    RowsNormArgs n2;
+    n2.x_in = w.xd; n2.ld_in = d; n2.add_bias = L.proj_l.bias; n2.partials = w.slab_b; n2.num_partials = ks_proj; n2.partial_rows = B;
+    n2.ld_partial = d; n2.x_out = w.xd; n2.ld_out = d; n2.y = w.hd; n2.ld_y = d; n2.M = B; n2.d = d; n2.mode = NORM_LN;
+    n2.g1 = L.ln2_g; n2.b1 = L.ln2_b;
+    if (rows_norm_forward(n2, st)) return 1;
+    Gemv16Args fa;
+    fa.x = w.hd; fa.ldx = d; fa.ypart = w.slab_a; fa.rows = B; fa.ksplit = ks_fc;
+    if (gemv16_forward(L.fc_g, fa, st)) return 1;
+    Gemv16Args fb;     // input = gelu_new(sum_s slab_a + c_fc bias), fused into the staging prologue
+    fb.xpart = w.slab_a; fb.xparts = ks_fc; fb.xpart_rows = B; fb.ld_xpart = f; fb.xbias = L.fc_l.bias; fb.xact = 1;
+    fb.ypart = w.slab_b; fb.rows = B; fb.ksplit = ks_fc2;
+    if (gemv16_forward(L.fc2_g, fb, st)) return 1;
+  }
+  RowsNormArgs nf;    // last layer's mlp.c_proj folded into the head norm
+  nf.x_in = w.xd; nf.ld_in = d; nf.add_bias = layers.back().fc2_l.bias; nf.partials = w.slab_b; nf.num_partials = ks_fc2;
+  nf.partial_rows = B; nf.ld_partial = d;
+  if (head_and_sample(w, B, nf, penalty, codes, codes_ld, logits_base, st)) return 1;
+  return advance_state(w.state, st);
+}
+
+int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int B, int P, int max_new, float penalty,
+                       long long* codes, int* n_steps_out, float* logits_out, void* ws, size_t ws_bytes, int use_graph,
+                       hipStream_t st) {
+  IDX_CHECK(inputs_embeds && codes && n_steps_out, "null pointer");
+  IDX_CHECK(B > 0 && B <= 64 && P > 0 && max_new > 0, "shape (1 <= B <= 64)");
+  const int d = cfg.model_dim, V = cfg.number_mel_codes, S = P + 1;
+  IDX_CHECK(max_new + 1 < cfg.mel_pos_len, "max_new_tokens exceeds the mel position table");
+  IDX_CHECK(ws && ws_bytes >= workspace_bytes(B, S, max_new), "workspace too small");
+  Buffers w = carve(ws, B, S, max_new);
+
+  // ---- per-call state ----
+  std::vector<int> kstart(B, 0);
+  if (pad_left_host) for (int b = 0; b < B; ++b) kstart[b] = pad_left_host[b];
+  for (int b = 0; b < B; ++b) IDX_CHECK(kstart[b] >= 0 && kstart[b] < P, "pad_left out of range");
+  IDX_HIP(hipMemcpyAsync(w.kstart, kstart.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
+  IDX_HIP(hipMemsetAsync(w.finished, 0, B * sizeof(int), st));
+  // input_ids of the reference = fake prefix of 1s + start_mel_token: both count for the repetition penalty
+  std::vector<unsigned char> seen((size_t)B * V, 0);
+  for (int b = 0; b < B; ++b) { seen[(size_t)b * V + 1] = 1; seen[(size_t)b * V + cfg.start_mel_token] = 1; }
+  IDX_HIP(hipMemcpyAsync(w.seen, seen.data(), seen.size(), hipMemcpyHostToDevice, st));
+  DecodeState s0{P, 1, 0, 0};
+  IDX_HIP(hipMemcpyAsync(w.state, &s0, sizeof(s0), hipMemcpyHostToDevice, st));
+  IDX_HIP(hipStreamSynchronize(st));   // host staging buffers go out of scope below
+
+  // ---- prefill: x = [inputs_embeds | mel_emb[start] + mel_pos[0]] ----
+  IDX_HIP(hipMemcpy2DAsync(w.x, (size_t)S * d * sizeof(float), inputs_embeds, (size_t)P * d * sizeof(float),
+                           (size_t)P * d * sizeof(float), B, hipMemcpyDeviceToDevice, st));
+  {
+    std::vector<int> tok(B, cfg.start_mel_token);
+    IDX_HIP(hipMemcpyAsync(w.cur_tok, tok.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
+    IDX_HIP(hipStreamSynchronize(st));
+    DecodeState zero{0, 0, 0, 0};
+    (void)zero;
+    // reuse embed_step with a temporary state whose mel_pos = 0: state currently has mel_pos = 1, so gather directly
+    GatherArgs ga;
+    ga.out = w.x + (size_t)P * d; ga.ld_out = S * d; ga.d = d;
+    ga.table[0] = mel_emb; ga.idx[0] = w.cur_tok;           // start_mel_token rows
+    ga.table[1] = mel_pos; ga.idx[1] = w.finished;          // all zeros -> mel position 0
+    if (gather_sum_rows(ga, B, st)) return 1;
+  }
+  for (int li = 0; li < cfg.layers; ++li)
+    if (layer_full(li, w, B, S, w.kstart, true, st)) return 1;
+  {
+    RowsNormArgs nl;
+    nl.x_in = w.x + (size_t)(S - 1) * d; nl.ld_in = S * d;   // last position of every row
+    if (head_and_sample(w, B, nl, penalty, codes, max_new, logits_out, st)) return 1;
+    if (advance_state(w.state, st)) return 1;
+  }
+
+  // ---- decode ----
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  const bool graph_ok = use_graph && !logits_out && !prof_enabled();
+  int n_first = 1;
+  if (graph_ok && max_new > 2) {
+    // step 1 runs eagerly (first-use function attributes are set outside the capture), steps >= 2 replay
+    if (decode_step(w, B, penalty, codes, max_new, nullptr, st)) return 1;
+    n_first = 2;
+    IDX_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = decode_step(w, B, penalty, codes, max_new, nullptr, st);
+    hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc) return 1;
+    IDX_HIP(e);
+    IDX_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  }
+  std::vector<int> fin(B);
+  int steps_done = n_first;
+  for (int n = n_first; n < max_new; ++n) {
+    if (exec) {
+      IDX_HIP(hipGraphLaunch(exec, st));
+    } else {
+      float* lo = logits_out ? logits_out + (size_t)n * B * V : nullptr;
+      if (decode_step(w, B, penalty, codes, max_new, lo, st)) return 1;
+    }
+    steps_done = n + 1;
+    if ((n & 15) == 15 || n + 1 == max_new) {     // all rows finished? (HF stops there; later columns would be pad)
+      IDX_HIP(hipMemcpyAsync(fin.data(), w.finished, B * sizeof(int), hipMemcpyDeviceToHost, st));
+      IDX_HIP(hipStreamSynchronize(st));
+      bool all = true;
+      for (int b = 0; b < B; ++b) all = all && fin[b];
+      if (all) break;
+    }
+  }
+  if (exec) (void)hipGraphExecDestroy(exec);
+  if (graph) (void)hipGraphDestroy(graph);
+  // exact HF length: generation stops at the first step after which every row has emitted the stop token
+  std::vector<long long> hc((size_t)B * max_new);
+  IDX_HIP(hipMemcpyAsync(hc.data(), codes, hc.size() * sizeof(long long), hipMemcpyDeviceToHost, st));
+  IDX_HIP(hipStreamSynchronize(st));
+  int n_steps = steps_done;
+  int worst = 0;
+  bool every_row_stops = true;
+  for (int b = 0; b < B; ++b) {
+    int first = -1;
+    for (int s = 0; s < steps_done; ++s)
+      if (hc[(size_t)b * max_new + s] == cfg.stop_mel_token) { first = s; break; }
+    if (first < 0) every_row_stops = false;
+    else worst = std::max(worst, first + 1);
+  }
+  if (every_row_stops) n_steps = worst;
+  *n_steps_out = n_steps;
+  return 0;
+}
+
+int GPTModel::latent(const float* emb, int B, int S, int mel_start, int M, float* latent_out, void* ws, size_t ws_bytes,
+                     hipStream_t st) {
+  IDX_CHECK(emb && latent_out, "null pointer");
+  IDX_CHECK(B > 0 && S > 0 && M > 0 && mel_start >= 0 && mel_start + M <= S, "shape");
+  IDX_CHECK(ws && ws_bytes >= workspace_bytes(B, S, 0), "workspace too small");
+  const int d = cfg.model_dim;
+  Buffers w = carve(ws, B, S, 0);
+  IDX_HIP(hipMemcpyAsync(w.x, emb, (size_t)B * S * d * sizeof(float), hipMemcpyDeviceToDevice, st));
+  for (int li = 0; li < cfg.layers; ++li)
+    if (layer_full(li, w, B, S, nullptr, false, st)) return 1;
+  RowsNormArgs n;     // final_norm(ln_f(h)) on the mel rows only (model_v2.py:611, 723)
+  n.x_in = w.x + (size_t)mel_start * d; n.ld_in = d; n.in_rows_per_batch = M; n.in_batch_stride = (long)S * d;
+  n.y = latent_out; n.ld_y = d; n.M = B * M; n.d = d; n.mode = NORM_LN_LN;
+  n.g1 = lnf_g; n.b1 = lnf_b; n.g2 = fn_g; n.b2 = fn_b;
+  return rows_norm_forward(n, st);
+}
+
+int GPTModel::embed(float* out, int rows, const int* text_ids, const int* text_pos_idx, const int* mel_ids, const int* mel_pos_idx,
+                    const float* extra, const int* extra_idx, hipStream_t st) {
+  GatherArgs ga;
+  ga.out = out; ga.ld_out = cfg.model_dim; ga.d = cfg.model_dim;
+  ga.table[0] = text_emb; ga.idx[0] = text_ids;
+  ga.table[1] = text_pos; ga.idx[1] = text_pos_idx;
+  ga.table[2] = mel_emb; ga.idx[2] = mel_ids;
+  ga.table[3] = mel_pos; ga.idx[3] = mel_pos_idx;
+  ga.table[4] = extra; ga.idx[4] = extra_idx;
+  return gather_sum_rows(ga, rows, st);
+}
+
+}  // namespace idxtts

@@ -1,0 +1,149 @@
+// Row-wise normalisation with fused residual-stream bookkeeping (one 256-thread workgroup per row).
+//
+//   x   = x_in[m] (+ add_bias) (+ sum_s partial[s][m])          -> optionally written back (residual stream)
+//   y   = norm(x)                                               -> input of the next GEMM / GEMV
+// norm modes (reference call sites):
+//   NORM_NONE       y = x
+//   NORM_LN         torch LayerNorm(eps)                 GPT-2 ln_1 / ln_2 / ln_f (transformers_gpt2.py:615-674, 1171)
+//   NORM_LN_LN      LN(g1,b1) then LN(g2,b2)             ln_f followed by final_norm (model_v2.py:208, 562, 611)
+//   NORM_ADA_RMS    wmod[b] * (x * rsqrt(mean x^2 + eps) * g1) + bmod[b]
+//                                                        AdaptiveLayerNorm(RMSNorm) (gpt_fast/model.py:20-38, 322-333)
+//   NORM_MOD_LN     LN(no affine, eps) * (1 + scale[b]) + shift[b]      FinalLayer (diffusion_transformer.py:84-101)
+// The split-K partial sum is what lets the skinny decode GEMVs (gemv16.hip) stay atomics-free and
+// bitwise reproducible: their K-slices are combined here, in the next kernel's prologue, in a fixed order.
+// Reductions: per-thread partial -> wave64 shuffle tree -> one LDS exchange between the 4 waves.
+#include "norm.h"
+#include "prof.h"
+
+namespace idxtts {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {   // 256 threads
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();                 // protect `red` from the previous use
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+constexpr int NORM_MAX_PER_THREAD = 32;   // d <= 8192
+
+// NPER = elements per thread (compile-time so v[] stays in registers: a runtime-bounded array would
+// be demoted to scratch memory)
+template <int NPER>
+__global__ __launch_bounds__(256) void rows_norm_kernel(const RowsNormArgs p) {
+  __shared__ float red[4];
+  const int m = blockIdx.x, tid = threadIdx.x, d = p.d;
+  constexpr int nper = NPER;
+  float v[NPER];
+  const float* xin = nullptr;
+  if (p.x_in) {
+    if (p.in_rows_per_batch > 0) {
+      const int bb = m / p.in_rows_per_batch;
+      xin = p.x_in + (size_t)bb * p.in_batch_stride + (size_t)(m - bb * p.in_rows_per_batch) * p.ld_in;
+    } else {
+      xin = p.x_in + (size_t)m * p.ld_in;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < nper; ++i) {
+    const int e = tid + (i << 8);
+    float a = 0.0f;
+    if (e < d) {
+      if (xin) a = xin[e];
+      if (p.add_bias) a += p.add_bias[e];
+      for (int s = 0; s < p.num_partials; ++s) a += p.partials[((size_t)s * p.partial_rows + m) * p.ld_partial + e];
+      if (p.x_out) p.x_out[(size_t)m * p.ld_out + e] = a;
+    }
+    v[i] = a;
+  }
+  if (p.mode == NORM_NONE || !p.y) {
+    if (p.y)
+#pragma unroll
+      for (int i = 0; i < nper; ++i) { const int e = tid + (i << 8); if (e < d) p.y[(size_t)m * p.ld_y + e] = v[i]; }
+    return;
+  }
+  const float inv_d = 1.0f / d;
+  const int b = p.rows_per_batch > 0 ? m / p.rows_per_batch : 0;
+  if (p.mode == NORM_ADA_RMS) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < nper; ++i) { const int e = tid + (i << 8); if (e < d) ss += v[i] * v[i]; }
+    const float r = rsqrtf(block_sum(ss, red) * inv_d + p.eps);
+    const float* wm = p.mod_a ? p.mod_a + (size_t)b * p.ld_mod : nullptr;
+    const float* bm = p.mod_b ? p.mod_b + (size_t)b * p.ld_mod : nullptr;
+#pragma unroll
+    for (int i = 0; i < nper; ++i) {
+      const int e = tid + (i << 8);
+      if (e < d) {
+        float o = v[i] * r * p.g1[e];
+        if (wm) o = wm[e] * o + bm[e];
+        p.y[(size_t)m * p.ld_y + e] = o;
+      }
+    }
+    return;
+  }
+  // LayerNorm family: two-pass (mean, then centred variance), as torch does
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < nper; ++i) { const int e = tid + (i << 8); if (e < d) s += v[i]; }
+  const float mean = block_sum(s, red) * inv_d;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < nper; ++i) { const int e = tid + (i << 8); if (e < d) { const float c = v[i] - mean; ss += c * c; } }
+  const float rstd = rsqrtf(block_sum(ss, red) * inv_d + p.eps);
+  if (p.mode == NORM_MOD_LN) {
+    const float* sh = p.mod_a + (size_t)b * p.ld_mod;   // shift
+    const float* sc = p.mod_b + (size_t)b * p.ld_mod;   // scale
+#pragma unroll
+    for (int i = 0; i < nper; ++i) {
+      const int e = tid + (i << 8);
+      if (e < d) p.y[(size_t)m * p.ld_y + e] = (v[i] - mean) * rstd * (1.0f + sc[e]) + sh[e];
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < nper; ++i) { const int e = tid + (i << 8); if (e < d) v[i] = (v[i] - mean) * rstd * p.g1[e] + p.b1[e]; }
+  if (p.mode == NORM_LN_LN) {
+    s = 0.f;
+#pragma unroll
+    for (int i = 0; i < nper; ++i) { const int e = tid + (i << 8); if (e < d) s += v[i]; }
+    const float mean2 = block_sum(s, red) * inv_d;
+    ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < nper; ++i) { const int e = tid + (i << 8); if (e < d) { const float c = v[i] - mean2; ss += c * c; } }
+    const float rstd2 = rsqrtf(block_sum(ss, red) * inv_d + p.eps2);
+#pragma unroll
+    for (int i = 0; i < nper; ++i) { const int e = tid + (i << 8); if (e < d) v[i] = (v[i] - mean2) * rstd2 * p.g2[e] + p.b2[e]; }
+  }
+#pragma unroll
+  for (int i = 0; i < nper; ++i) { const int e = tid + (i << 8); if (e < d) p.y[(size_t)m * p.ld_y + e] = v[i]; }
+}
+
+int rows_norm_forward(const RowsNormArgs& a, hipStream_t stream) {
+  if (a.M == 0) return 0;
+  IDX_CHECK(a.M > 0 && a.d > 0 && a.d <= 256 * NORM_MAX_PER_THREAD, "rows_norm shape");
+  IDX_CHECK(a.x_in || a.num_partials > 0 || a.add_bias, "rows_norm needs an input");
+  if (a.mode == NORM_LN || a.mode == NORM_LN_LN) IDX_CHECK(a.g1 && a.b1, "LayerNorm needs weight and bias");
+  if (a.mode == NORM_LN_LN) IDX_CHECK(a.g2 && a.b2, "second LayerNorm needs weight and bias");
+  if (a.mode == NORM_ADA_RMS) IDX_CHECK(a.g1 && (!a.mod_a == !a.mod_b), "RMSNorm needs a weight (and both or no modulation vectors)");
+  if (a.mode == NORM_MOD_LN) IDX_CHECK(a.mod_a && a.mod_b, "modulated LN needs shift and scale");
+  const double bytes = 4.0 * a.M * (double)a.d * (1.0 + a.num_partials + (a.x_out ? 1 : 0) + (a.y ? 1 : 0));
+  ProfScope prof(PROF_ROWS_NORM, stream, 0.0, bytes);
+  const int nper = (a.d + 255) / 256;
+  if (nper <= 2) hipLaunchKernelGGL(rows_norm_kernel<2>, dim3(a.M), dim3(256), 0, stream, a);
+  else if (nper <= 5) hipLaunchKernelGGL(rows_norm_kernel<5>, dim3(a.M), dim3(256), 0, stream, a);
+  else if (nper <= 8) hipLaunchKernelGGL(rows_norm_kernel<8>, dim3(a.M), dim3(256), 0, stream, a);
+  else if (nper <= 20) hipLaunchKernelGGL(rows_norm_kernel<20>, dim3(a.M), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(rows_norm_kernel<NORM_MAX_PER_THREAD>, dim3(a.M), dim3(256), 0, stream, a);
+  IDX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace idxtts

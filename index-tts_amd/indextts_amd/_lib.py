@@ -19,6 +19,8 @@ SYMBOLS = [
     "idxtts_ctx_load_tensor", "idxtts_ctx_finalize", "idxtts_ctx_destroy",
     "idxtts_bigvgan_create", "idxtts_bigvgan_workspace_bytes", "idxtts_bigvgan_fwd",
     "idxtts_profile_enable", "idxtts_profile_num_kernels", "idxtts_profile_kernel_name", "idxtts_profile_read",
+    "idxtts_linear_create", "idxtts_linear_fwd", "idxtts_linear_destroy", "idxtts_attention_fwd", "idxtts_layernorm_fwd",
+    "idxtts_gpt_create", "idxtts_gpt_workspace_bytes", "idxtts_gpt_embed", "idxtts_gpt_generate", "idxtts_gpt_latent",
 ]
 
 
@@ -29,6 +31,11 @@ class BigVGANConfigC(ctypes.Structure):
         ("num_kernels", c_int), ("resblock_kernel_sizes", c_int * 4),
         ("resblock_dilations", (c_int * 3) * 4),
     ]
+
+
+class GPTConfigC(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("model_dim", "heads", "layers", "number_mel_codes", "number_text_tokens",
+                                     "start_mel_token", "stop_mel_token", "mel_pos_len", "text_pos_len")]
 
 
 _lib = None
@@ -60,6 +67,20 @@ def load() -> ctypes.CDLL:
     lib.idxtts_bigvgan_workspace_bytes.restype = c_size_t
     lib.idxtts_bigvgan_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_int, c_int,
                                        c_void_p, c_void_p]
+    c_long = ctypes.c_long
+    lib.idxtts_linear_create.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_void_p)]
+    lib.idxtts_linear_fwd.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]
+    lib.idxtts_linear_destroy.argtypes = [c_void_p]
+    lib.idxtts_attention_fwd.argtypes = [c_void_p] * 4 + [c_long, c_int, c_long, c_int, c_long, c_int, c_int, c_int, c_int, c_int,
+                                                          c_int, c_void_p, c_void_p, c_float, c_void_p]
+    lib.idxtts_layernorm_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]
+    lib.idxtts_gpt_create.argtypes = [POINTER(GPTConfigC), POINTER(c_void_p)]
+    lib.idxtts_gpt_workspace_bytes.argtypes = [c_void_p, c_int, c_int, c_int]
+    lib.idxtts_gpt_workspace_bytes.restype = c_size_t
+    lib.idxtts_gpt_embed.argtypes = [c_void_p, c_void_p, c_int] + [c_void_p] * 7
+    lib.idxtts_gpt_generate.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, POINTER(c_int),
+                                        c_void_p, c_void_p, c_size_t, c_int, c_void_p]
+    lib.idxtts_gpt_latent.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.idxtts_profile_enable.argtypes = [c_int]
     lib.idxtts_profile_kernel_name.argtypes = [c_int]
     lib.idxtts_profile_kernel_name.restype = c_char_p

@@ -78,7 +78,7 @@ class GPTConfig:
 
     @staticmethod
     def tiny() -> "GPTConfig":
-        return GPTConfig(model_dim=128, heads=4, layers=3, number_text_tokens=300,
+        return GPTConfig(model_dim=128, heads=2, layers=3, number_text_tokens=300,
                          number_mel_codes=258, start_mel_token=256, stop_mel_token=257,
                          max_mel_tokens=120, max_text_tokens=60, cond_latents=6)
 
@@ -123,7 +123,7 @@ class S2MelConfig:
 
     @staticmethod
     def tiny() -> "S2MelConfig":
-        return S2MelConfig(hidden_dim=64, num_heads=2, depth=5, in_channels=16, content_dim=64,
+        return S2MelConfig(hidden_dim=128, num_heads=2, depth=5, in_channels=16, content_dim=64,
                            style_dim=24, block_size=512, wn_hidden=64, wn_layers=3,
                            lr_channels=64, lr_in_channels=96, gpt_dim=128,
                            gpt_layer_dims=(48, 32, 96), codebook_size=256, codebook_dim=8,

@@ -1,0 +1,214 @@
+"""Host-side mirror of the reference's GPT interface (indextts/gpt/model_v2.py), backed by libidxtts_hip.
+
+`UnifiedVoice` keeps the reference's method names and argument meaning for the hot path:
+  * prepare_gpt_inputs(conditional_latents, text_inputs)           model_v2.py:725-794
+  * inference_speech(..., text_inputs, emo_vec=..., **generate kw)  model_v2.py:796-895 (greedy path)
+  * forward(...) -> latent                                          model_v2.py:673-723
+  * accel_engine-style generate(input_ids, max_new_tokens, ..., attention_mask, tts_embeddings, ...)
+                                                                    accel/accel_engine.py:378-645 (plugin slot)
+Difference, by scope: the conformer/perceiver conditioning encoders are not part of
+this hot path, so `speech_conditioning_latent` [B,32,d] and `emo_vec` [B,d] are INPUTS here, where the
+reference derives them from the prompt audio once per prompt (model_v2.py:819-828, 897-910).
+All arithmetic runs in the HIP kernels; numpy/torch only build int32 index arrays and own the buffers.
+"""
+from __future__ import annotations
+
+import ctypes
+import warnings
+from ctypes import c_void_p
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import GPTConfig
+
+
+def _i32(dev, arr) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)).to(dev)
+
+
+class UnifiedVoice:
+    def __init__(self, state_dict, cfg: GPTConfig = GPTConfig(), device="cuda:0"):
+        lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("the HIP GPT path needs a ROCm GPU device; there is no CPU fallback")
+        c = _lib.GPTConfigC(cfg.model_dim, cfg.heads, cfg.layers, cfg.number_mel_codes, cfg.number_text_tokens,
+                            cfg.start_mel_token, cfg.stop_mel_token, cfg.mel_pos_len, cfg.text_pos_len)
+        h = c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.idxtts_gpt_create(ctypes.byref(c), ctypes.byref(h)))
+            self._h = h
+            sd = {k: v for k, v in state_dict.items() if self._on_path(k)}
+            _lib.load_state_dict(h, sd)
+        se = state_dict["speed_emb.weight"]
+        self.speed_emb = (se if isinstance(se, torch.Tensor) else torch.from_numpy(np.asarray(se))).float().to(self.device)
+        self._ws = None
+        self.stop_mel_token = cfg.stop_mel_token
+        self.start_mel_token = cfg.start_mel_token
+        self.accel_engine = self       # the reference selects `self.accel_engine.generate` (model_v2.py:871)
+
+    @staticmethod
+    def _on_path(key: str) -> bool:
+        return key.startswith(("gpt.h.", "gpt.ln_f.", "final_norm.", "mel_head.", "mel_embedding.", "text_embedding.",
+                               "mel_pos_embedding.", "text_pos_embedding.", "speed_emb."))
+
+    # ------------------------------------------------------------------------------------------
+    def _workspace(self, B: int, S: int, max_new: int) -> torch.Tensor:
+        need = int(_lib.load().idxtts_gpt_workspace_bytes(self._h, B, S, max_new))
+        if need == 0:
+            raise RuntimeError("idxtts_gpt_workspace_bytes returned 0")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _embed(self, rows: int, text_ids=None, text_pos=None, mel_ids=None, mel_pos=None, extra=None, extra_idx=None):
+        out = torch.empty(rows, self.cfg.model_dim, device=self.device, dtype=torch.float32)
+        idx = [None if a is None else _i32(self.device, a) for a in (text_ids, text_pos, mel_ids, mel_pos, extra_idx)]
+        ex = None if extra is None else extra.to(self.device, torch.float32).contiguous()
+        _lib.check(_lib.load().idxtts_gpt_embed(self._h, _lib.ptr(out), rows, _lib.ptr(idx[0]), _lib.ptr(idx[1]), _lib.ptr(idx[2]),
+                                                _lib.ptr(idx[3]), _lib.ptr(ex), _lib.ptr(idx[4]), _lib.current_stream()))
+        return out
+
+    def conds_latent(self, speech_conditioning_latent: torch.Tensor, emo_vec: torch.Tensor) -> torch.Tensor:
+        """cat(latent + emo_vec, speed_emb(1), speed_emb(0)) -> [B, 34, d]   (model_v2.py:830-834)."""
+        lat = speech_conditioning_latent.to(self.device, torch.float32)
+        B = lat.shape[0]
+        se = self.speed_emb
+        return torch.cat([lat + emo_vec.to(self.device, torch.float32)[:, None, :], se[1].expand(B, 1, -1),
+                          se[0].expand(B, 1, -1)], dim=1).contiguous()
+
+    def prepare_gpt_inputs(self, conditional_latents: torch.Tensor, text_inputs: torch.Tensor):
+        """model_v2.py:725-794 -> (fake_inputs [B,P+1], inputs_embeds [B,P,d] on the GPU, attention_mask [B,P+1])."""
+        cfg = self.cfg
+        text = text_inputs.detach().cpu().numpy().astype(np.int64)
+        B, L = text.shape
+        nc = conditional_latents.shape[1]
+        single = conditional_latents.shape[0] == 1
+        if not single and conditional_latents.shape[0] != B:
+            raise AssertionError(f"batch size mismatch: {conditional_latents.shape[0]} vs {B}")
+        P = nc + L + 2
+        tid = -np.ones((B, P), np.int32)
+        tpos = -np.ones((B, P), np.int32)
+        eidx = -np.ones((B, P), np.int32)
+        mask = np.ones((B, P + 1), np.int64)
+        for i in range(B):
+            ti = text[i]
+            ti = ti[(ti != cfg.stop_text_token) & (ti != cfg.start_text_token)]
+            ti = np.concatenate([[cfg.start_text_token], ti, [cfg.stop_text_token]])
+            pad = L + 2 - len(ti)
+            mask[i, :pad] = 0
+            eidx[i, pad:pad + nc] = np.arange(nc) + (0 if single else i * nc)
+            tid[i, pad + nc:] = ti
+            tpos[i, pad + nc:] = np.arange(len(ti))
+        extra = conditional_latents.reshape(-1, cfg.model_dim)
+        emb = self._embed(B * P, text_ids=tid.reshape(-1), text_pos=tpos.reshape(-1), extra=extra, extra_idx=eidx.reshape(-1))
+        fake = torch.ones(B, P + 1, dtype=torch.long)
+        fake[:, -1] = cfg.start_mel_token
+        return fake, emb.view(B, P, cfg.model_dim), torch.from_numpy(mask)
+
+    # ------------------------------------------------------------------------------------------
+    def generate(self, input_ids: torch.Tensor, max_new_tokens: int = 100, temperature: float = 1.0, top_k: int = 50,
+                 top_p: float = 1.0, stop_tokens=None, attention_mask: Optional[torch.Tensor] = None,
+                 tts_embeddings: Optional[torch.Tensor] = None, tts_mel_embedding=None, tts_text_pos_embedding=None,
+                 repetition_penalty: float = 10.0, return_logits: bool = False, use_graph: bool = True) -> torch.Tensor:
+        """The accel-engine plugin contract (accel_engine.py:378-645): returns LongTensor [B, P+1+generated]
+        (prompt ids followed by the generated codes, padded with the stop token).  Greedy only."""
+        if tts_embeddings is None:
+            raise ValueError("tts_embeddings ([pad][cond][text] prompt embeddings) is required")
+        if stop_tokens is not None and list(stop_tokens) != [self.cfg.stop_mel_token]:
+            raise ValueError("stop_tokens must be [stop_mel_token]")
+        emb = tts_embeddings.to(self.device, torch.float32).contiguous()
+        B, P, d = emb.shape
+        if input_ids.shape != (B, P + 1):
+            raise ValueError("input_ids must be [B, P+1] (fake prefix + start_mel_token)")
+        pad_left = np.zeros(B, np.int32)
+        if attention_mask is not None:
+            am = attention_mask.detach().cpu().numpy()
+            pad_left = (am[:, :P] == 0).sum(1).astype(np.int32)
+        codes = torch.full((B, max_new_tokens), self.cfg.stop_mel_token, dtype=torch.long, device=self.device)
+        V = self.cfg.number_mel_codes
+        logits = torch.zeros(max_new_tokens, B, V, device=self.device) if return_logits else None
+        ws = self._workspace(B, P + 1, max_new_tokens)
+        n = ctypes.c_int(0)
+        _lib.check(_lib.load().idxtts_gpt_generate(
+            self._h, _lib.ptr(emb), pad_left.ctypes.data_as(c_void_p), B, P, max_new_tokens, float(repetition_penalty),
+            _lib.ptr(codes), ctypes.byref(n), _lib.ptr(logits), _lib.ptr(ws), ws.numel(), int(use_graph), _lib.current_stream()))
+        out = torch.cat([input_ids.to(self.device), codes[:, : n.value]], dim=1)
+        if return_logits:
+            return out, logits[: n.value].permute(1, 0, 2).contiguous()
+        return out
+
+    def inference_speech(self, speech_conditioning_latent, text_inputs, emo_vec=None, max_generate_length=None,
+                         num_return_sequences=1, return_logits=False, **hf_generate_kwargs):
+        """Greedy `inference_speech` (model_v2.py:796-895): returns (codes [B, n], speech_conditioning_latent)."""
+        if hf_generate_kwargs.pop("do_sample", False) or hf_generate_kwargs.pop("num_beams", 1) != 1:
+            raise NotImplementedError("only greedy decoding (do_sample=False, num_beams=1) is implemented on the HIP path "
+                                      "(beam-sample is SURVEY §8f rank 2)")
+        if num_return_sequences != 1:
+            raise NotImplementedError("num_return_sequences must be 1")
+        penalty = float(hf_generate_kwargs.pop("repetition_penalty", 1.0))
+        for k in ("top_p", "top_k", "temperature", "length_penalty"):
+            hf_generate_kwargs.pop(k, None)
+        if hf_generate_kwargs:
+            raise TypeError(f"unsupported generate kwargs: {sorted(hf_generate_kwargs)}")
+        conds = self.conds_latent(speech_conditioning_latent, emo_vec)
+        input_ids, inputs_embeds, attention_mask = self.prepare_gpt_inputs(conds, text_inputs)
+        trunc_index = input_ids.shape[1]
+        max_new = (self.cfg.max_mel_tokens - 1) if max_generate_length is None else int(max_generate_length)
+        out = self.generate(input_ids, max_new_tokens=max_new, stop_tokens=[self.cfg.stop_mel_token],
+                            attention_mask=attention_mask, tts_embeddings=inputs_embeds, repetition_penalty=penalty,
+                            return_logits=return_logits)
+        if return_logits:
+            return out[0][:, trunc_index:], speech_conditioning_latent, out[1]
+        return out[:, trunc_index:], speech_conditioning_latent
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, speech_conditioning_latent, text_inputs, text_lengths, mel_codes, mel_codes_lengths,
+                emo_speech_conditioning_latent=None, cond_mel_lengths=None, emo_cond_mel_lengths=None, emo_vec=None,
+                use_speed=None, do_spk_cond=False) -> torch.Tensor:
+        """Latent pass (model_v2.py:673-723) -> [B, M, d]."""
+        if do_spk_cond or emo_vec is None:
+            raise NotImplementedError("conditioning encoders are outside this hot path: pass the latent and emo_vec")
+        cfg = self.cfg
+        text = text_inputs.detach().cpu().numpy().astype(np.int64).copy()
+        codes = mel_codes.detach().cpu().numpy().astype(np.int64).copy()
+        B, L = text.shape
+        M = codes.shape[1]
+        tl = np.asarray(text_lengths.detach().cpu() if isinstance(text_lengths, torch.Tensor) else text_lengths).reshape(-1)
+        ml = np.asarray(mel_codes_lengths.detach().cpu() if isinstance(mel_codes_lengths, torch.Tensor) else mel_codes_lengths).reshape(-1)
+        for b in range(B):      # set_text_padding / set_mel_padding (model_v2.py:569-595)
+            text[b, int(tl[min(b, len(tl) - 1)]):] = cfg.stop_text_token
+            codes[b, int(ml[min(b, len(ml) - 1)]):] = cfg.stop_mel_token
+        tin = np.concatenate([np.full((B, 1), cfg.start_text_token), text, np.full((B, 1), cfg.stop_text_token)], 1)
+        min_ = np.concatenate([np.full((B, 1), cfg.start_mel_token), codes, np.full((B, 1), cfg.stop_mel_token)], 1)
+        conds = self.conds_latent(speech_conditioning_latent, emo_vec)
+        nc = conds.shape[1]
+        S = nc + L + 2 + M + 2
+        tid = -np.ones((B, S), np.int32); tpos = -np.ones((B, S), np.int32)
+        mid = -np.ones((B, S), np.int32); mpos = -np.ones((B, S), np.int32)
+        eidx = -np.ones((B, S), np.int32)
+        for b in range(B):
+            eidx[b, :nc] = np.arange(nc) + b * nc
+            tid[b, nc:nc + L + 2] = tin[b]; tpos[b, nc:nc + L + 2] = np.arange(L + 2)
+            mid[b, nc + L + 2:] = min_[b]; mpos[b, nc + L + 2:] = np.arange(M + 2)
+        emb = self._embed(B * S, tid.reshape(-1), tpos.reshape(-1), mid.reshape(-1), mpos.reshape(-1),
+                          conds.reshape(-1, cfg.model_dim), eidx.reshape(-1))
+        latent = torch.empty(B, M, cfg.model_dim, device=self.device, dtype=torch.float32)
+        ws = self._workspace(B, S, 0)
+        _lib.check(_lib.load().idxtts_gpt_latent(self._h, _lib.ptr(emb), B, S, nc + L + 2, M, _lib.ptr(latent), _lib.ptr(ws),
+                                                 ws.numel(), _lib.current_stream()))
+        return latent
+
+    __call__ = forward
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.load().idxtts_ctx_destroy(self._h)
+        except Exception:
+            pass

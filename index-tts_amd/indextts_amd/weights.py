@@ -59,3 +59,46 @@ def synth_bigvgan_weights(cfg: BigVGANConfig, tag: str = "bigvgan") -> Weights:
 def synth_mel(name: str, batch: int, num_mels: int, frames: int) -> np.ndarray:
     """Log-mel-like input: BASELINE.md config 2 uses randn*1.5-4; here the same range, uniform."""
     return synth.uniform(name, (batch, num_mels, frames), scale=2.6, offset=-4.0)
+
+
+# --------------------------------------------------------------------------------------
+# GPT (UnifiedVoice hot-path tensors; model_v2.py:381-443, HF GPT2Model built at model_v2.py:290-305)
+# --------------------------------------------------------------------------------------
+def synth_gpt_weights(cfg: GPTConfig, tag: str = "gpt") -> Weights:
+    """Keys/shapes of `UnifiedVoice.state_dict()` restricted to the decode + latent-pass path.
+    HF `Conv1D` weights are [in, out] (y = x @ W + b)."""
+    w: Weights = {}
+    d, f = cfg.model_dim, cfg.ffn_dim
+
+    def u(name, shape, scale, offset=0.0):
+        w[name] = synth.uniform(f"{tag}/{name}", shape, scale, offset)
+
+    def lin(name, shape, fan_in, gain=1.0):
+        w[name] = synth.fan_in_uniform(f"{tag}/{name}", shape, fan_in, gain)
+
+    for i in range(cfg.layers):
+        p = f"gpt.h.{i}"
+        u(f"{p}.ln_1.weight", (d,), 0.2, 1.0)
+        u(f"{p}.ln_1.bias", (d,), 0.1)
+        lin(f"{p}.attn.c_attn.weight", (d, 3 * d), d, 1.2)
+        u(f"{p}.attn.c_attn.bias", (3 * d,), 0.1)
+        lin(f"{p}.attn.c_proj.weight", (d, d), d, 0.7)
+        u(f"{p}.attn.c_proj.bias", (d,), 0.05)
+        u(f"{p}.ln_2.weight", (d,), 0.2, 1.0)
+        u(f"{p}.ln_2.bias", (d,), 0.1)
+        lin(f"{p}.mlp.c_fc.weight", (d, f), d, 1.0)
+        u(f"{p}.mlp.c_fc.bias", (f,), 0.1)
+        lin(f"{p}.mlp.c_proj.weight", (f, d), f, 0.7)
+        u(f"{p}.mlp.c_proj.bias", (d,), 0.05)
+    u("gpt.ln_f.weight", (d,), 0.2, 1.0)
+    u("gpt.ln_f.bias", (d,), 0.1)
+    u("final_norm.weight", (d,), 0.2, 1.0)
+    u("final_norm.bias", (d,), 0.1)
+    lin("mel_head.weight", (cfg.number_mel_codes, d), d, 3.0)
+    u("mel_head.bias", (cfg.number_mel_codes,), 0.5)
+    u("mel_embedding.weight", (cfg.number_mel_codes, d), 0.6)
+    u("text_embedding.weight", (cfg.number_text_tokens + 1, d), 0.6)
+    u("mel_pos_embedding.emb.weight", (cfg.mel_pos_len, d), 0.3)
+    u("text_pos_embedding.emb.weight", (cfg.text_pos_len, d), 0.3)
+    u("speed_emb.weight", (2, d), 0.1)
+    return w

@@ -1,0 +1,194 @@
+"""ORACLE (test infrastructure, not product): CPU fp32 restatement of the IndexTTS-2 GPT stage.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this.
+
+What it restates (reference file:line, relative to grantjr1842/index-tts):
+  * GPT-2 block arithmetic      in-tree spec indextts/gpt/transformers_gpt2.py:196-234 (attention),
+                                578-592 (MLP, gelu_new), 615-674 (block), 1171 (ln_f); the module
+                                actually instantiated is third-party `transformers==4.52.1` GPT2Model
+                                (model_v2.py:290-305; wpe nulled 300-302)
+  * prepare_gpt_inputs          indextts/gpt/model_v2.py:725-794
+  * GPT2InferenceModel.forward  model_v2.py:131-225 (prefill 162-172, decode 173-177: the mel position
+                                index is attention_mask.shape[1] - mel_len, i.e. 0, 2, 3, 4, ...)
+  * greedy loop                 indextts/gpt/transformers_generation_utils.py:3196-3269 with the
+                                RepetitionPenalty processor (900-901; HF semantics: score<0 ? score*p : score/p
+                                over every id in input_ids, including the fake all-ones prefix and 8192)
+  * latent pass                 UnifiedVoice.forward model_v2.py:673-723, get_logits 597-625
+PARITY PIN: the reference's own tests hold no numeric fixture for this stage and model_v2.py cannot be
+imported here (transformers 5.x vs pinned 4.52.1), so the block arithmetic is pinned against the
+container's `transformers.GPT2Model` + `RepetitionPenaltyLogitsProcessor` (tests/golden/make_golden.py
+-> gpt.npz), the wrapper semantics against the text of model_v2.py cited above.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _t(w, key) -> torch.Tensor:
+    v = w[key]
+    return v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))
+
+
+def gelu_new(x: torch.Tensor) -> torch.Tensor:
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
+
+
+def gpt2_stack(w, cfg, emb: torch.Tensor, key_valid: Optional[torch.Tensor] = None,
+               past: Optional[list] = None) -> Tuple[torch.Tensor, list]:
+    """emb [B,S,d] (already includes the learned positions; HF wpe is nulled) -> ln_f(hidden) [B,S,d].
+
+    key_valid: [B, past_len+S] bool/0-1 (the HF `attention_mask`), None = all valid.
+    past: per-layer (K,V) each [B,H,past_len,hd].  Returns (hidden, present)."""
+    B, S, d = emb.shape
+    H, hd = cfg.heads, cfg.head_dim
+    past_len = 0 if past is None else past[0][0].shape[2]
+    total = past_len + S
+    qpos = torch.arange(past_len, total)[:, None]
+    kpos = torch.arange(total)[None, :]
+    allowed = (kpos <= qpos)[None, None]                                   # causal [1,1,S,total]
+    if key_valid is not None:
+        allowed = allowed & key_valid.bool()[:, None, None, :]
+    x = emb
+    present = []
+    for i in range(cfg.layers):
+        p = f"gpt.h.{i}"
+        h = F.layer_norm(x, (d,), _t(w, f"{p}.ln_1.weight"), _t(w, f"{p}.ln_1.bias"), 1e-5)
+        qkv = h @ _t(w, f"{p}.attn.c_attn.weight") + _t(w, f"{p}.attn.c_attn.bias")
+        q, k, v = qkv.split(d, dim=2)
+        q = q.view(B, S, H, hd).transpose(1, 2)
+        k = k.view(B, S, H, hd).transpose(1, 2)
+        v = v.view(B, S, H, hd).transpose(1, 2)
+        if past is not None:
+            k = torch.cat([past[i][0], k], dim=2)
+            v = torch.cat([past[i][1], v], dim=2)
+        present.append((k, v))
+        scores = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+        scores = torch.where(allowed, scores, torch.full_like(scores, torch.finfo(scores.dtype).min))
+        att = torch.softmax(scores, dim=-1)
+        a = (att @ v).transpose(1, 2).reshape(B, S, d)
+        a = a @ _t(w, f"{p}.attn.c_proj.weight") + _t(w, f"{p}.attn.c_proj.bias")
+        x = x + a
+        h = F.layer_norm(x, (d,), _t(w, f"{p}.ln_2.weight"), _t(w, f"{p}.ln_2.bias"), 1e-5)
+        m = gelu_new(h @ _t(w, f"{p}.mlp.c_fc.weight") + _t(w, f"{p}.mlp.c_fc.bias"))
+        m = m @ _t(w, f"{p}.mlp.c_proj.weight") + _t(w, f"{p}.mlp.c_proj.bias")
+        x = x + m
+    x = F.layer_norm(x, (d,), _t(w, "gpt.ln_f.weight"), _t(w, "gpt.ln_f.bias"), 1e-5)
+    return x, present
+
+
+def lm_head(w, cfg, hidden: torch.Tensor) -> torch.Tensor:
+    """lm_head = Sequential(final_norm, mel_head) applied AFTER ln_f (model_v2.py:208, 562)."""
+    d = cfg.model_dim
+    h = F.layer_norm(hidden, (d,), _t(w, "final_norm.weight"), _t(w, "final_norm.bias"), 1e-5)
+    return h @ _t(w, "mel_head.weight").t() + _t(w, "mel_head.bias")
+
+
+def conds_latent(w, cfg, speech_conditioning_latent: torch.Tensor, emo_vec: torch.Tensor) -> torch.Tensor:
+    """model_v2.py:830-834: cat(latent + emo_vec, speed_emb(1), speed_emb(0)) -> [B, 34, d]."""
+    B = speech_conditioning_latent.shape[0]
+    se = _t(w, "speed_emb.weight")
+    return torch.cat([speech_conditioning_latent + emo_vec[:, None, :],
+                      se[1][None, None, :].expand(B, 1, -1), se[0][None, None, :].expand(B, 1, -1)], dim=1)
+
+
+def prepare_gpt_inputs(w, cfg, conds: torch.Tensor, text_inputs: torch.Tensor):
+    """model_v2.py:725-794 -> (fake_inputs [B,P+1], inputs_embeds [B,P,d], attention_mask [B,P+1])."""
+    B, L = text_inputs.shape
+    single = conds.shape[0] == 1
+    target_len = conds.shape[1] + L + 2
+    te, tp = _t(w, "text_embedding.weight"), _t(w, "text_pos_embedding.emb.weight")
+    embs, masks = [], []
+    for i in range(B):
+        ti = text_inputs[i]
+        ti = ti[(ti != cfg.stop_text_token) & (ti != cfg.start_text_token)]
+        ti = F.pad(F.pad(ti, (1, 0), value=cfg.start_text_token), (0, 1), value=cfg.stop_text_token)
+        temb = te[ti.long()] + tp[: ti.shape[0]]
+        parts = [conds[0] if single else conds[i], temb]
+        mask = torch.ones(target_len + 1, dtype=torch.long)
+        padding = L + 2 - ti.shape[0]
+        if padding > 0:
+            parts.insert(0, torch.zeros(padding, conds.shape[-1]))
+            mask[:padding] = 0
+        embs.append(torch.cat(parts))
+        masks.append(mask)
+    inputs_embeds = torch.stack(embs)
+    attention_mask = torch.stack(masks)
+    fake = torch.ones(B, target_len + 1, dtype=torch.long)
+    fake[:, -1] = cfg.start_mel_token
+    return fake, inputs_embeds, attention_mask
+
+
+def repetition_penalty(input_ids: torch.Tensor, scores: torch.Tensor, penalty: float) -> torch.Tensor:
+    """HF RepetitionPenaltyLogitsProcessor: gather, rescale, scatter."""
+    s = torch.gather(scores, 1, input_ids)
+    s = torch.where(s < 0, s * penalty, s / penalty)
+    return scores.scatter(1, input_ids, s)
+
+
+def generate_greedy(w, cfg, conds: torch.Tensor, text_inputs: torch.Tensor, max_new_tokens: int,
+                    repetition_penalty_value: float = 10.0, return_logits: bool = False):
+    """inference_speech (model_v2.py:835-892) with do_sample=False, num_beams=1.
+    Returns codes [B, n_steps] (eos and post-eos pad = stop_mel_token included, as HF returns them)."""
+    fake, inputs_embeds, attention_mask = prepare_gpt_inputs(w, cfg, conds, text_inputs)
+    B, P, d = inputs_embeds.shape
+    me, mp = _t(w, "mel_embedding.weight"), _t(w, "mel_pos_embedding.emb.weight")
+    input_ids = fake.clone()
+    unfinished = torch.ones(B, dtype=torch.long)
+    past = None
+    all_logits = []
+    for step in range(max_new_tokens):
+        if past is None:     # prefill: cached [pad|cond|text] embeddings + start_mel at mel position 0
+            start = (me[cfg.start_mel_token] + mp[0])[None, None, :].expand(B, 1, d)
+            emb = torch.cat([inputs_embeds, start], dim=1)
+        else:                # decode: position = attention_mask.shape[1] - mel_len  (model_v2.py:175-177)
+            pos = attention_mask.shape[1] - P
+            emb = (me[input_ids[:, -1]] + mp[pos])[:, None, :]
+        hidden, past = gpt2_stack(w, cfg, emb, attention_mask, past)
+        logits = lm_head(w, cfg, hidden[:, -1]).float()
+        if return_logits:
+            all_logits.append(logits.clone())
+        scores = repetition_penalty(input_ids, logits, repetition_penalty_value) if repetition_penalty_value != 1.0 else logits
+        nxt = torch.argmax(scores, dim=-1)
+        nxt = nxt * unfinished + cfg.stop_mel_token * (1 - unfinished)
+        input_ids = torch.cat([input_ids, nxt[:, None]], dim=1)
+        attention_mask = torch.cat([attention_mask, torch.ones(B, 1, dtype=torch.long)], dim=1)
+        unfinished = unfinished & (nxt != cfg.stop_mel_token).long()
+        if unfinished.max() == 0:
+            break
+    codes = input_ids[:, P + 1:]
+    return (codes, torch.stack(all_logits, 1)) if return_logits else codes
+
+
+def latent_forward(w, cfg, speech_conditioning_latent: torch.Tensor, text_inputs: torch.Tensor,
+                   mel_codes: torch.Tensor, emo_vec: torch.Tensor,
+                   text_lengths: Optional[torch.Tensor] = None,
+                   mel_lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """UnifiedVoice.forward (model_v2.py:673-723) with do_spk_cond=False, emo_vec given -> latent [B,M,d]."""
+    B, L = text_inputs.shape
+    M = mel_codes.shape[1]
+    text_inputs = text_inputs.clone().long()
+    mel_codes = mel_codes.clone().long()
+    if text_lengths is not None:       # set_text_padding (model_v2.py:583-595)
+        for b in range(B):
+            text_inputs[b, int(text_lengths[b]):] = cfg.stop_text_token
+    if mel_lengths is not None:        # set_mel_padding (569-581)
+        for b in range(B):
+            mel_codes[b, int(mel_lengths[b]):] = cfg.stop_mel_token
+    text_inputs = F.pad(text_inputs, (0, 1), value=cfg.stop_text_token)
+    mel_codes = F.pad(mel_codes, (0, 1), value=cfg.stop_mel_token)
+    conds = conds_latent(w, cfg, speech_conditioning_latent, emo_vec)
+    text_in = F.pad(text_inputs, (1, 0), value=cfg.start_text_token)      # build_aligned_inputs_and_targets
+    mel_in = F.pad(mel_codes, (1, 0), value=cfg.start_mel_token)
+    text_emb = _t(w, "text_embedding.weight")[text_in] + _t(w, "text_pos_embedding.emb.weight")[: L + 2]
+    mel_emb = _t(w, "mel_embedding.weight")[mel_in] + _t(w, "mel_pos_embedding.emb.weight")[: M + 2]
+    emb = torch.cat([conds, text_emb, mel_emb], dim=1)
+    hidden, _ = gpt2_stack(w, cfg, emb)
+    enc = F.layer_norm(hidden[:, conds.shape[1]:], (cfg.model_dim,), _t(w, "final_norm.weight"),
+                       _t(w, "final_norm.bias"), 1e-5)
+    mel_part = enc[:, -(M + 2):]
+    return mel_part[:, :-2]

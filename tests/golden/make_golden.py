@@ -28,6 +28,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "index-tts_amd"))
+sys.path.insert(0, ROOT)
 REF = "/root/reference"
 
 
@@ -121,13 +122,105 @@ def make_vocoder():
     print("wrote vocoder.npz", {k: v.shape for k, v in out.items()})
 
 
+# ----------------------------------------------------------------------------------------------
+def make_gpt():
+    """GPT-2 stack fixtures from the container's `transformers.GPT2Model` (the reference instantiates the
+    same class from transformers==4.52.1 at model_v2.py:290-305) + HF's RepetitionPenaltyLogitsProcessor."""
+    import functools
+    from transformers import GPT2Config, GPT2Model
+    from transformers.cache_utils import DynamicCache
+    from transformers.generation.logits_process import RepetitionPenaltyLogitsProcessor
+    import torch.nn.functional as F
+    from indextts_amd import synth, weights
+    from indextts_amd.config import GPTConfig
+
+    def null_position_embeddings(range, dim):          # model_v2.py:32-33
+        return torch.zeros((range.shape[0], range.shape[1], dim), device=range.device)
+
+    cfg = GPTConfig.tiny()
+    d = cfg.model_dim
+    w = weights.synth_gpt_weights(cfg, tag="golden/gpt")
+    seq = cfg.max_mel_tokens + cfg.max_text_tokens + 2
+    gc = GPT2Config(vocab_size=256, n_positions=seq, n_ctx=seq, n_embd=d, n_layer=cfg.layers, n_head=cfg.heads,
+                    use_cache=True, attn_pdrop=0.0, embd_pdrop=0.0, resid_pdrop=0.0)
+    gpt = GPT2Model(gc).eval()
+    del gpt.wpe
+    gpt.wpe = functools.partial(null_position_embeddings, dim=d)
+    del gpt.wte
+    sd = {k[len("gpt."):]: torch.from_numpy(v) for k, v in w.items() if k.startswith("gpt.")}
+    missing, unexpected = gpt.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(("attn.bias" in m or "masked_bias" in m) for m in missing), missing
+    tw = {k: torch.from_numpy(v) for k, v in w.items()}
+
+    def head(h):
+        h = F.layer_norm(h, (d,), tw["final_norm.weight"], tw["final_norm.bias"], 1e-5)
+        return h @ tw["mel_head.weight"].t() + tw["mel_head.bias"]
+
+    out = {}
+    # ---- greedy decode: B=3 rows, the second and third left-padded (ragged text lengths) ----
+    B, L, NEW = 3, 12, 10
+    P = cfg.cond_latents + 2 + L + 2
+    conds = torch.from_numpy(synth.uniform("golden/gpt/conds", (B, cfg.cond_latents + 2, d), 0.5))
+    text = torch.from_numpy(synth.integers("golden/gpt/text", (B, L), 2, cfg.number_text_tokens))
+    text[1, 9:] = cfg.stop_text_token       # row 1 has 9 real tokens, row 2 has 5
+    text[2, 5:] = cfg.stop_text_token
+    # inputs_embeds / mask built exactly as model_v2.py:749-779 describes (restated in oracle.gpt; checked there)
+    from oracle import gpt as og
+    fake, inputs_embeds, attention_mask = og.prepare_gpt_inputs(tw, cfg, conds, text)
+    me, mp = tw["mel_embedding.weight"], tw["mel_pos_embedding.emb.weight"]
+    proc = RepetitionPenaltyLogitsProcessor(penalty=10.0)
+    input_ids = fake.clone()
+    cache = DynamicCache()
+    logits_all = []
+    unfinished = torch.ones(B, dtype=torch.long)
+    with torch.no_grad():
+        for step in range(NEW):
+            if step == 0:
+                emb = torch.cat([inputs_embeds, (me[cfg.start_mel_token] + mp[0])[None, None].expand(B, 1, d)], 1)
+            else:
+                emb = (me[input_ids[:, -1]] + mp[attention_mask.shape[1] - P])[:, None]
+            o = gpt(inputs_embeds=emb, past_key_values=cache, attention_mask=attention_mask, use_cache=True, return_dict=True)
+            cache = o.past_key_values
+            logits = head(o.last_hidden_state[:, -1]).float()
+            logits_all.append(logits.clone())
+            scores = proc(input_ids, logits.clone())
+            nxt = torch.argmax(scores, -1)
+            nxt = nxt * unfinished + cfg.stop_mel_token * (1 - unfinished)
+            input_ids = torch.cat([input_ids, nxt[:, None]], 1)
+            attention_mask = torch.cat([attention_mask, torch.ones(B, 1, dtype=torch.long)], 1)
+            unfinished = unfinished & (nxt != cfg.stop_mel_token).long()
+    out["greedy_codes"] = input_ids[:, P + 1:].numpy()
+    out["greedy_logits"] = torch.stack(logits_all, 1).numpy()
+    out["greedy_text"] = text.numpy()
+    # ---- latent pass (no mask, causal): B=2, L=7, M=9 ----
+    B2, L2, M2 = 2, 7, 9
+    lat = torch.from_numpy(synth.uniform("golden/gpt/lat", (B2, cfg.cond_latents, d), 0.5))
+    emo = torch.from_numpy(synth.uniform("golden/gpt/emo", (B2, d), 0.3))
+    text2 = torch.from_numpy(synth.integers("golden/gpt/text2", (B2, L2), 2, cfg.number_text_tokens))
+    codes2 = torch.from_numpy(synth.integers("golden/gpt/codes2", (B2, M2), 0, cfg.start_mel_token))
+    conds2 = og.conds_latent(tw, cfg, lat, emo)
+    tin = F.pad(F.pad(text2, (0, 1), value=cfg.stop_text_token), (1, 0), value=cfg.start_text_token)
+    min_ = F.pad(F.pad(codes2, (0, 1), value=cfg.stop_mel_token), (1, 0), value=cfg.start_mel_token)
+    emb = torch.cat([conds2, tw["text_embedding.weight"][tin] + tw["text_pos_embedding.emb.weight"][: L2 + 2],
+                     me[min_] + mp[: M2 + 2]], 1)
+    with torch.no_grad():
+        hs = gpt(inputs_embeds=emb, return_dict=True).last_hidden_state
+    enc = F.layer_norm(hs[:, conds2.shape[1]:], (d,), tw["final_norm.weight"], tw["final_norm.bias"], 1e-5)
+    out["latent"] = enc[:, -(M2 + 2):][:, :-2].numpy()
+    out["latent_hidden"] = hs.numpy()
+    np.savez_compressed(os.path.join(HERE, "gpt.npz"), **out)
+    print("wrote gpt.npz", {k: v.shape for k, v in out.items()}, "codes", out["greedy_codes"].tolist())
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    Munch = _install_placeholders()
     torch.manual_seed(0)
-    if which in ("vocoder", "all"):
-        make_vocoder()
-    if which in ("s2mel", "all") and "make_s2mel" in globals():
-        globals()["make_s2mel"](Munch)
-    if which in ("gpt", "all") and "make_gpt" in globals():
-        globals()["make_gpt"]()
+    if which in ("gpt", "all"):          # before the placeholders: transformers probes for torchaudio
+        make_gpt()
+    if which in ("vocoder", "s2mel", "all"):
+        Munch = _install_placeholders()
+        if which in ("vocoder", "all"):
+            make_vocoder()
+        if which in ("s2mel", "all") and "make_s2mel" in globals():
+            globals()["make_s2mel"](Munch)

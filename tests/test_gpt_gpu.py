@@ -1,0 +1,195 @@
+"""GPU parity: token-major building blocks (GEMM, attention, LayerNorm) and the GPT stage (greedy decode,
+latent pass) through the C ABI, against torch fp64/fp32 CPU references, the CPU oracle and the HF golden vectors."""
+import ctypes
+import math
+import os
+from ctypes import c_void_p
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from indextts_amd import _lib, synth, weights
+from indextts_amd.config import GPTConfig
+
+pytestmark = pytest.mark.gpu
+
+
+def _linear(device, w, b, x, act=0, res=None, kn=False):
+    lib = _lib.load()
+    N, K = (w.shape[1], w.shape[0]) if kn else w.shape
+    h = c_void_p()
+    wd = w.contiguous()
+    _lib.check(lib.idxtts_linear_create(_lib.ptr(wd), _lib.ptr(b), N, K, int(kn), ctypes.byref(h)))
+    xd = x.to(device).contiguous()
+    M = xd.shape[0]
+    No = N // 2 if act == 3 else N
+    y = torch.empty(M, No, device=device)
+    rd = None if res is None else res.to(device).contiguous()
+    _lib.check(lib.idxtts_linear_fwd(h, _lib.ptr(xd), xd.shape[1], _lib.ptr(y), No, _lib.ptr(rd), No, M, act, _lib.current_stream()))
+    out = y.cpu()
+    lib.idxtts_linear_destroy(h)
+    return out
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 4), (7, 40, 36), (128, 128, 128), (300, 1280, 256), (165, 3840, 1280), (1000, 512, 864),
+                                   (129, 80, 512), (64, 8194, 128)])
+def test_gemm_tn_vs_torch(device, shape):
+    M, N, K = shape
+    x = torch.from_numpy(synth.uniform(f"t/gemm/x/{shape}", (M, K), 1.0))
+    w = torch.from_numpy(synth.fan_in_uniform(f"t/gemm/w/{shape}", (N, K), K))
+    b = torch.from_numpy(synth.uniform(f"t/gemm/b/{shape}", (N,), 0.2))
+    ref = (x.double() @ w.double().t() + b.double()).float()
+    y = _linear(device, w, b, x)
+    assert (y - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    # HF Conv1D layout + gelu_new + residual
+    r = torch.from_numpy(synth.uniform(f"t/gemm/r/{shape}", (M, N), 1.0))
+    pre = x.double() @ w.double().t() + b.double()
+    gelu = 0.5 * pre * (1 + torch.tanh(math.sqrt(2 / math.pi) * (pre + 0.044715 * pre ** 3)))
+    y2 = _linear(device, w.t().contiguous(), b, x, act=1, res=r, kn=True)
+    assert (y2 - (gelu + r.double()).float()).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_gemm_swiglu_and_silu(device):
+    M, Hd, K = 200, 192, 64      # hidden 192 -> N = 384 packed as [32 w1 | 32 w3] blocks
+    x = torch.from_numpy(synth.uniform("t/swiglu/x", (M, K), 1.0))
+    w1 = torch.from_numpy(synth.fan_in_uniform("t/swiglu/w1", (Hd, K), K, 2.0))
+    w3 = torch.from_numpy(synth.fan_in_uniform("t/swiglu/w3", (Hd, K), K, 2.0))
+    packed = torch.stack([w1.view(Hd // 32, 32, K), w3.view(Hd // 32, 32, K)], dim=1).reshape(2 * Hd, K)
+    y = _linear(device, packed, None, x, act=3)
+    ref = (F.silu(x.double() @ w1.double().t()) * (x.double() @ w3.double().t())).float()
+    assert (y - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    ys = _linear(device, w1, None, x, act=2)
+    assert (ys - F.silu(x.double() @ w1.double().t()).float()).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("cfg", [(2, 2, 37, True, True), (1, 4, 165, True, False), (3, 2, 300, False, True), (2, 8, 129, False, False),
+                                 (1, 2, 1, True, False), (1, 1, 700, True, True)])
+def test_attention_vs_torch(device, cfg):
+    B, H, S, causal, ragged = cfg
+    d = H * 64
+    qkv = torch.from_numpy(synth.uniform(f"t/attn/qkv/{cfg}", (B, S, 3 * d), 1.5))
+    kstart = torch.zeros(B, dtype=torch.int32)
+    kend = torch.full((B,), S, dtype=torch.int32)
+    if ragged:
+        for b in range(B):
+            if causal:
+                kstart[b] = (b * 5 + 3) % max(1, S // 2)       # left padding (GPT prompts)
+            else:
+                kend[b] = S - (b * 7) % max(1, S // 2)         # right padding (DiT x_lens)
+    q, k, v = (t.view(B, S, H, 64).transpose(1, 2).double() for t in qkv.split(d, dim=2))
+    pos = torch.arange(S)
+    allowed = (pos[None, :] >= kstart[:, None]) & (pos[None, :] < kend[:, None])          # [B,S] keys
+    allowed = allowed[:, None, None, :].expand(B, 1, S, S)
+    if causal:
+        allowed = allowed & (pos[None, :] <= pos[:, None])[None, None]
+    scores = (q @ k.transpose(-1, -2)) / 8.0
+    scores = scores.masked_fill(~allowed, float("-inf"))
+    att = torch.softmax(scores, -1)
+    att = torch.nan_to_num(att, nan=0.0)            # rows with no visible key -> zeros (kernel convention)
+    ref = (att @ v).transpose(1, 2).reshape(B, S, d).float()
+    lib = _lib.load()
+    qd = qkv.to(device).contiguous()
+    o = torch.empty(B, S, d, device=device)
+    ks, ke = kstart.to(device), kend.to(device)
+    base = qd.data_ptr()
+    _lib.check(lib.idxtts_attention_fwd(c_void_p(base), c_void_p(base + 4 * d), c_void_p(base + 8 * d), _lib.ptr(o), S * 3 * d, 3 * d,
+                                        S * 3 * d, 3 * d, S * d, d, B, H, S, S, int(causal), _lib.ptr(ks), _lib.ptr(ke), 0.125,
+                                        _lib.current_stream()))
+    got = o.cpu()
+    valid = allowed.any(-1)[:, 0, :]                 # [B,S] query rows with at least one key
+    err = ((got - ref).abs() * valid[:, :, None]).max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert (got[~valid].abs().max().item() if (~valid).any() else 0.0) == 0.0
+
+
+def test_layernorm_vs_torch(device):
+    for (M, d) in [(5, 128), (33, 1280), (4, 5120), (3, 512)]:
+        x = torch.from_numpy(synth.uniform(f"t/ln/x/{M}/{d}", (M, d), 3.0, 0.7))
+        g = torch.from_numpy(synth.uniform(f"t/ln/g/{d}", (d,), 0.5, 1.0))
+        b = torch.from_numpy(synth.uniform(f"t/ln/b/{d}", (d,), 0.5))
+        y = torch.empty(M, d, device=device)
+        _lib.check(_lib.load().idxtts_layernorm_fwd(_lib.ptr(x.to(device)), _lib.ptr(y), _lib.ptr(g.to(device)), _lib.ptr(b.to(device)),
+                                                    M, d, 1e-5, _lib.current_stream()))
+        ref = F.layer_norm(x.double(), (d,), g.double(), b.double(), 1e-5).float()
+        assert (y.cpu() - ref).abs().max().item() <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+def _tiny(golden_dir, device):
+    from indextts_amd.gpt import UnifiedVoice
+    g = np.load(os.path.join(golden_dir, "gpt.npz"))
+    cfg = GPTConfig.tiny()
+    w = weights.synth_gpt_weights(cfg, tag="golden/gpt")
+    return g, cfg, w, UnifiedVoice(w, cfg, device=device)
+
+
+def test_greedy_codes_bit_exact_vs_hf_golden(device, golden_dir):
+    g, cfg, w, uv = _tiny(golden_dir, device)
+    B, L = g["greedy_text"].shape
+    NEW = g["greedy_codes"].shape[1]
+    conds = torch.from_numpy(synth.uniform("golden/gpt/conds", (B, cfg.cond_latents + 2, cfg.model_dim), 0.5)).to(device)
+    text = torch.from_numpy(g["greedy_text"])
+    fake, emb, mask = uv.prepare_gpt_inputs(conds, text)
+    for graph in (False, True):
+        out = uv.generate(fake, max_new_tokens=NEW, stop_tokens=[cfg.stop_mel_token], attention_mask=mask, tts_embeddings=emb,
+                          repetition_penalty=10.0, use_graph=graph)
+        codes = out[:, fake.shape[1]:].cpu().numpy()
+        assert np.array_equal(codes, g["greedy_codes"]), f"graph={graph}"       # token indices: bit-exact
+    out, logits = uv.generate(fake, max_new_tokens=NEW, stop_tokens=[cfg.stop_mel_token], attention_mask=mask, tts_embeddings=emb,
+                              repetition_penalty=10.0, return_logits=True)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["greedy_logits"], rtol=0, atol=5e-4)
+
+
+def test_prepare_inputs_matches_oracle(device, golden_dir):
+    from oracle import gpt as og
+    g, cfg, w, uv = _tiny(golden_dir, device)
+    conds = torch.from_numpy(synth.uniform("golden/gpt/conds", (3, cfg.cond_latents + 2, cfg.model_dim), 0.5))
+    text = torch.from_numpy(g["greedy_text"])
+    fake, emb, mask = uv.prepare_gpt_inputs(conds.to(device), text)
+    tw = {k: torch.from_numpy(v) for k, v in w.items()}
+    f2, e2, m2 = og.prepare_gpt_inputs(tw, cfg, conds, text)
+    assert torch.equal(fake, f2) and torch.equal(mask, m2)
+    assert torch.equal(emb.cpu(), e2)        # pure gathers + one add: bit-exact
+
+
+def test_latent_pass_vs_golden(device, golden_dir):
+    g, cfg, w, uv = _tiny(golden_dir, device)
+    B, M, d = g["latent"].shape
+    lat = torch.from_numpy(synth.uniform("golden/gpt/lat", (B, cfg.cond_latents, d), 0.5))
+    emo = torch.from_numpy(synth.uniform("golden/gpt/emo", (B, d), 0.3))
+    text = torch.from_numpy(synth.integers("golden/gpt/text2", (B, 7), 2, cfg.number_text_tokens))
+    codes = torch.from_numpy(synth.integers("golden/gpt/codes2", (B, M), 0, cfg.start_mel_token))
+    out = uv.forward(lat, text, torch.tensor([7, 7]), codes, torch.tensor([M, M]), emo_vec=emo)
+    np.testing.assert_allclose(out.cpu().numpy(), g["latent"], rtol=0, atol=5e-5)
+
+
+def test_eos_and_padding_invariance(device):
+    """Rows that stop keep emitting the stop token; a row decoded alone equals the same row left-padded in a batch
+    (the reference's own property test, tests/padding_test.py:35-89); results equal the CPU oracle token for token."""
+    from indextts_amd.gpt import UnifiedVoice
+    from oracle import gpt as og
+    cfg = GPTConfig.tiny()
+    w = weights.synth_gpt_weights(cfg, tag="t/gpt/eos")
+    w["mel_head.bias"] = w["mel_head.bias"].copy()
+    w["mel_head.bias"][cfg.stop_mel_token] = 3.5
+    uv = UnifiedVoice(w, cfg, device=device)
+    tw = {k: torch.from_numpy(v) for k, v in w.items()}
+    B, L = 5, 9
+    lat = torch.from_numpy(synth.uniform("t/gpt/eos/lat", (B, cfg.cond_latents, cfg.model_dim), 0.5))
+    emo = torch.from_numpy(synth.uniform("t/gpt/eos/emo", (B, cfg.model_dim), 0.3))
+    text = torch.from_numpy(synth.integers("t/gpt/eos/text", (B, L), 2, cfg.number_text_tokens))
+    text[1, 6:] = cfg.stop_text_token
+    text[3, 2:] = cfg.stop_text_token
+    codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=48, repetition_penalty=10.0)
+    ref = og.generate_greedy(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, 48, 10.0)
+    assert np.array_equal(codes.cpu().numpy(), ref.numpy())
+    c = codes.cpu().numpy()
+    for row in c:
+        hits = np.nonzero(row == cfg.stop_mel_token)[0]
+        if len(hits):
+            assert (row[hits[0]:] == cfg.stop_mel_token).all()
+    solo, _ = uv.inference_speech(lat[3:4], text[3:4, :2], emo_vec=emo[3:4], max_generate_length=c.shape[1], repetition_penalty=10.0)
+    n = min(solo.shape[1], c.shape[1])
+    assert np.array_equal(solo.cpu().numpy()[0, :n], c[3, :n])
