@@ -24,6 +24,8 @@ struct GPTModel : ModelBase {
   const float* head_b = nullptr;
   const float *mel_emb = nullptr, *text_emb = nullptr, *mel_pos = nullptr, *text_pos = nullptr;
   int ks_attn = 1, ks_proj = 1, ks_fc = 1, ks_fc2 = 1, ks_head = 1;
+  hipStream_t own_stream = nullptr;
+  ~GPTModel() override { if (own_stream) (void)hipStreamDestroy(own_stream); }
 
   struct Buffers {
     float *x, *h, *qkv, *att, *ff;            // [B*S][..] prefill / latent activations

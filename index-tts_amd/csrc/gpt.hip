@@ -252,8 +252,16 @@ int GPTModel::decode_step(const Buffers& w, int B, float penalty, long long* cod
 
 int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int B, int P, int max_new, float penalty,
                        long long* codes, int* n_steps_out, float* logits_out, void* ws, size_t ws_bytes, int use_graph,
-                       hipStream_t st) {
+                       hipStream_t user_stream) {
   IDX_CHECK(inputs_embeds && codes && n_steps_out, "null pointer");
+  // The legacy default stream cannot be captured into a graph: run on a private stream, ordered after
+  // everything already queued by the caller (the call ends with a host sync anyway: n_steps is a host value).
+  hipStream_t st = user_stream;
+  if (user_stream == nullptr) {
+    if (!own_stream) IDX_HIP(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+    IDX_HIP(hipStreamSynchronize(user_stream));
+    st = own_stream;
+  }
   IDX_CHECK(B > 0 && B <= 64 && P > 0 && max_new > 0, "shape (1 <= B <= 64)");
   const int d = cfg.model_dim, V = cfg.number_mel_codes, S = P + 1;
   IDX_CHECK(max_new + 1 < cfg.mel_pos_len, "max_new_tokens exceeds the mel position table");

@@ -110,7 +110,8 @@ def test_layernorm_vs_torch(device):
         g = torch.from_numpy(synth.uniform(f"t/ln/g/{d}", (d,), 0.5, 1.0))
         b = torch.from_numpy(synth.uniform(f"t/ln/b/{d}", (d,), 0.5))
         y = torch.empty(M, d, device=device)
-        _lib.check(_lib.load().idxtts_layernorm_fwd(_lib.ptr(x.to(device)), _lib.ptr(y), _lib.ptr(g.to(device)), _lib.ptr(b.to(device)),
+        xd, gd, bd = x.to(device), g.to(device), b.to(device)     # keep the device copies alive across the launch
+        _lib.check(_lib.load().idxtts_layernorm_fwd(_lib.ptr(xd), _lib.ptr(y), _lib.ptr(gd), _lib.ptr(bd),
                                                     M, d, 1e-5, _lib.current_stream()))
         ref = F.layer_norm(x.double(), (d,), g.double(), b.double(), 1e-5).float()
         assert (y.cpu() - ref).abs().max().item() <= 1e-5
