@@ -124,7 +124,7 @@ class S2MelConfig:
     @staticmethod
     def tiny() -> "S2MelConfig":
         return S2MelConfig(hidden_dim=128, num_heads=2, depth=5, in_channels=16, content_dim=64,
-                           style_dim=24, block_size=512, wn_hidden=64, wn_layers=3,
+                           style_dim=24, block_size=512, wn_hidden=128, wn_layers=3,
                            lr_channels=64, lr_in_channels=96, gpt_dim=128,
                            gpt_layer_dims=(48, 32, 96), codebook_size=256, codebook_dim=8,
                            codec_hidden=96)

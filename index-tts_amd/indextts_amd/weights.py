@@ -102,3 +102,77 @@ def synth_gpt_weights(cfg: GPTConfig, tag: str = "gpt") -> Weights:
     u("text_pos_embedding.emb.weight", (cfg.text_pos_len, d), 0.3)
     u("speed_emb.weight", (2, d), 0.1)
     return w
+
+
+# --------------------------------------------------------------------------------------
+# s2mel (MyModel: cfm / length_regulator / gpt_layer, commons.py:390-420) + the semantic-codec
+# vq2emb tables (residual_vq.py:144-152, factorized_vector_quantize.py:123-127)
+# --------------------------------------------------------------------------------------
+def synth_s2mel_weights(cfg: S2MelConfig, tag: str = "s2mel") -> Weights:
+    """Keys follow `s2mel.pth['net'][{cfm,length_regulator,gpt_layer}]` prefixed with the sub-model name
+    (SURVEY.md §8a).  Weight-norm parametrised layers (final_layer.linear, wavenet.*) are stored FOLDED
+    under the plain `.weight` key; an exporter for a real checkpoint computes g*v/||v|| once."""
+    w: Weights = {}
+    D, H, F_, C = cfg.hidden_dim, cfg.num_heads, cfg.ffn_dim, cfg.in_channels
+
+    def lin(name, n_out, n_in, gain=1.0, bias=True, bscale=0.05):
+        w[f"{name}.weight"] = synth.fan_in_uniform(f"{tag}/{name}.weight", (n_out, n_in), n_in, gain)
+        if bias:
+            w[f"{name}.bias"] = synth.uniform(f"{tag}/{name}.bias", (n_out,), bscale)
+
+    def conv(name, cout, cin, k, gain=1.0):
+        w[f"{name}.weight"] = synth.fan_in_uniform(f"{tag}/{name}.weight", (cout, cin, k), cin * k, gain)
+        w[f"{name}.bias"] = synth.uniform(f"{tag}/{name}.bias", (cout,), 0.05)
+
+    # ---- DiT (diffusion_transformer.py:103-184) ----
+    e = "cfm.estimator"
+    for i in range(cfg.depth):
+        p = f"{e}.transformer.layers.{i}"
+        lin(f"{p}.attention.wqkv", 3 * D, D, 1.0, bias=False)
+        lin(f"{p}.attention.wo", D, D, 0.7, bias=False)
+        lin(f"{p}.feed_forward.w1", F_, D, 1.0, bias=False)
+        lin(f"{p}.feed_forward.w3", F_, D, 1.0, bias=False)
+        lin(f"{p}.feed_forward.w2", D, F_, 0.7, bias=False)
+        for nrm in ("attention_norm", "ffn_norm"):
+            lin(f"{p}.{nrm}.project_layer", 2 * D, D, 0.5, bscale=0.5)
+            w[f"{p}.{nrm}.project_layer.bias"][:D] += 1.0      # modulation weight ~ 1
+            w[f"{p}.{nrm}.norm.weight"] = synth.uniform(f"{tag}/{p}.{nrm}.norm.weight", (D,), 0.2, 1.0)
+        lin(f"{p}.skip_in_linear", D, 2 * D, 0.8)       # present in every block, used by blocks > depth//2
+    lin(f"{e}.transformer.norm.project_layer", 2 * D, D, 0.5, bscale=0.5)
+    w[f"{e}.transformer.norm.project_layer.bias"][:D] += 1.0
+    w[f"{e}.transformer.norm.norm.weight"] = synth.uniform(f"{tag}/{e}.transformer.norm.norm.weight", (D,), 0.2, 1.0)
+    lin(f"{e}.cond_projection", D, cfg.content_dim)
+    lin(f"{e}.cond_x_merge_linear", D, D + 2 * C + cfg.style_dim)
+    lin(f"{e}.t_embedder.mlp.0", D, 256)
+    lin(f"{e}.t_embedder.mlp.2", D, D)
+    lin(f"{e}.t_embedder2.mlp.0", cfg.wn_hidden, 256)
+    lin(f"{e}.t_embedder2.mlp.2", cfg.wn_hidden, cfg.wn_hidden)
+    lin(f"{e}.skip_linear", D, D + C)
+    lin(f"{e}.conv1", cfg.wn_hidden, D)
+    lin(f"{e}.res_projection", cfg.wn_hidden, D)
+    lin(f"{e}.final_layer.linear", cfg.wn_hidden, cfg.wn_hidden)             # weight-norm folded
+    lin(f"{e}.final_layer.adaLN_modulation.1", 2 * cfg.wn_hidden, cfg.wn_hidden, 0.5)
+    conv(f"{e}.conv2", C, cfg.wn_hidden, 1)
+    # ---- WaveNet (wavenet.py:103-136), weight-norm folded ----
+    Wh = cfg.wn_hidden
+    conv(f"{e}.wavenet.cond_layer.conv.conv", 2 * Wh * cfg.wn_layers, Wh, 1, 0.5)
+    for i in range(cfg.wn_layers):
+        conv(f"{e}.wavenet.in_layers.{i}.conv.conv", 2 * Wh, Wh, cfg.wn_kernel, 1.0)
+        conv(f"{e}.wavenet.res_skip_layers.{i}.conv.conv", 2 * Wh if i < cfg.wn_layers - 1 else Wh, Wh, 1, 0.6)
+    # ---- length regulator (length_regulator.py:28-88) ----
+    lr = "length_regulator"
+    lin(f"{lr}.content_in_proj", cfg.lr_channels, cfg.lr_in_channels)
+    for n in range(cfg.lr_num_convs):
+        conv(f"{lr}.model.{3 * n}", cfg.lr_channels, cfg.lr_channels, 3, 1.3)
+        w[f"{lr}.model.{3 * n + 1}.weight"] = synth.uniform(f"{tag}/{lr}.model.{3 * n + 1}.weight", (cfg.lr_channels,), 0.2, 1.0)
+        w[f"{lr}.model.{3 * n + 1}.bias"] = synth.uniform(f"{tag}/{lr}.model.{3 * n + 1}.bias", (cfg.lr_channels,), 0.1)
+    conv(f"{lr}.model.{3 * cfg.lr_num_convs}", cfg.lr_channels, cfg.lr_channels, 1)
+    # ---- gpt_layer (commons.py:413) ----
+    dims = (cfg.gpt_dim,) + tuple(cfg.gpt_layer_dims)
+    for n in range(3):
+        lin(f"gpt_layer.{n}", dims[n + 1], dims[n])
+    # ---- semantic codec vq2emb: codebook lookup + out_project (weight-norm folded 1x1 conv) ----
+    w["semantic_codec.quantizer.quantizers.0.codebook.weight"] = synth.uniform(
+        f"{tag}/semantic_codec.codebook", (cfg.codebook_size, cfg.codebook_dim), 1.0)
+    conv("semantic_codec.quantizer.quantizers.0.out_project", cfg.codec_hidden, cfg.codebook_dim, 1)
+    return w

@@ -123,6 +123,110 @@ def make_vocoder():
 
 
 # ----------------------------------------------------------------------------------------------
+def make_s2mel(Munch):
+    """s2mel fixtures from the reference's MyModel (cfm + length_regulator + gpt_layer) and the semantic codec's
+    FactorizedVectorQuantize.vq2emb, at reduced width (S2MelConfig.tiny())."""
+    from indextts_amd import synth, weights
+    from indextts_amd.config import S2MelConfig
+    from indextts.s2mel.modules.commons import MyModel
+    from indextts.utils.maskgct.models.codec.amphion_codec.quantize.factorized_vector_quantize import FactorizedVectorQuantize
+
+    cfg = S2MelConfig.tiny()
+
+    def to_m(d):
+        return Munch({k: to_m(v) for k, v in d.items()}) if isinstance(d, dict) else d
+
+    args = to_m({
+        "dit_type": "DiT", "reg_loss_type": "l1",
+        "style_encoder": {"dim": cfg.style_dim},
+        "length_regulator": {"channels": cfg.lr_channels, "is_discrete": False, "in_channels": cfg.lr_in_channels,
+                             "content_codebook_size": 2048, "sampling_ratios": [1] * cfg.lr_num_convs, "vector_quantize": False,
+                             "n_codebooks": 1, "quantizer_dropout": 0.0, "f0_condition": False, "n_f0_bins": 512},
+        "DiT": {"hidden_dim": cfg.hidden_dim, "num_heads": cfg.num_heads, "depth": cfg.depth, "class_dropout_prob": 0.1,
+                "block_size": 8192, "in_channels": cfg.in_channels, "style_condition": True, "final_layer_type": "wavenet",
+                "target": "mel", "content_dim": cfg.content_dim, "content_codebook_size": 1024, "content_type": "discrete",
+                "f0_condition": False, "n_f0_bins": 512, "content_codebooks": 1, "is_causal": False, "long_skip_connection": True,
+                "zero_prompt_speech_token": False, "time_as_token": False, "style_as_token": False, "uvit_skip_connection": True,
+                "add_resblock_in_transformer": False},
+        "wavenet": {"hidden_dim": cfg.wn_hidden, "num_layers": cfg.wn_layers, "kernel_size": cfg.wn_kernel,
+                    "dilation_rate": cfg.wn_dilation_rate, "p_dropout": 0.2, "style_condition": True},
+    })
+    mm = MyModel(args, use_gpt_latent=True)
+    # the reference hard-codes gpt_layer = Linear(1280,256) -> (256,128) -> (128,1024): rebuild at the tiny widths
+    dims = (cfg.gpt_dim,) + tuple(cfg.gpt_layer_dims)
+    mm.models["gpt_layer"] = torch.nn.Sequential(*[torch.nn.Linear(dims[i], dims[i + 1]) for i in range(3)])
+    mm.eval()
+    w = weights.synth_s2mel_weights(cfg, tag="golden/s2mel")
+    ref_sd = mm.state_dict()
+    new = {}
+    for k, v in ref_sd.items():
+        name = k[len("models."):]
+        if name.endswith("weight_g") or name.endswith("weight_v"):
+            base = name[: -len("_g")]                       # '....weight'
+            if base in w:
+                wt = torch.from_numpy(w[base])
+                if name.endswith("weight_v"):
+                    new[k] = wt
+                else:                                        # g = ||v|| over all dims but 0 -> g*v/||v|| == v
+                    new[k] = wt.reshape(wt.shape[0], -1).norm(dim=1).reshape(v.shape)
+            else:
+                new[k] = v                                   # x_embedder: unused in forward
+        elif name in w:
+            new[k] = torch.from_numpy(w[name])
+        else:
+            assert any(t in name for t in ("input_pos", "freqs", "cond_embedder", "content_mask_embedder", "mask_token",
+                                           "x_embedder", "embedding")), name
+            new[k] = v
+    mm.load_state_dict(new, strict=True)
+    used = {k[len("models."):].replace("weight_v", "weight").replace("weight_g", "weight") for k in ref_sd}
+    assert all(k in used or k.startswith("semantic_codec") for k in w), [k for k in w if k not in used and not k.startswith("semantic_codec")]
+    est = mm.models["cfm"].estimator
+    est.setup_caches(max_batch_size=2, max_seq_length=cfg.block_size)
+    # the reference builds the rotary table for block_size=16384 regardless of config; rows are position-indexed
+    out = {}
+    with torch.no_grad():
+        # (a) gpt_layer
+        lat = torch.from_numpy(synth.uniform("golden/s2mel/latent", (2, 9, cfg.gpt_dim), 1.0))
+        out["gpt_layer"] = mm.models["gpt_layer"](lat).numpy()
+        # (b) vq2emb
+        fvq = FactorizedVectorQuantize(input_dim=cfg.codec_hidden, codebook_size=cfg.codebook_size, codebook_dim=cfg.codebook_dim,
+                                       use_l2_normlize=True)
+        fvq.eval()
+        fvq.codebook.weight.data = torch.from_numpy(w["semantic_codec.quantizer.quantizers.0.codebook.weight"])
+        ow = torch.from_numpy(w["semantic_codec.quantizer.quantizers.0.out_project.weight"])
+        fvq.out_project.weight_v.data = ow
+        fvq.out_project.weight_g.data = ow.reshape(ow.shape[0], -1).norm(dim=1).reshape(fvq.out_project.weight_g.shape)
+        fvq.out_project.bias.data = torch.from_numpy(w["semantic_codec.quantizer.quantizers.0.out_project.bias"])
+        codes = torch.from_numpy(synth.integers("golden/s2mel/codes", (2, 9), 0, cfg.codebook_size))
+        out["vq2emb"] = fvq.vq2emb(codes).transpose(1, 2).numpy()            # [B,M,hidden] as infer_v2.py:841-842
+        # (c) length regulator, B=1 at two lengths (M=9 -> 15 frames, M=20 -> 34 frames)
+        for tag, M in (("a", 9), ("b", 20)):
+            S = torch.from_numpy(synth.uniform(f"golden/s2mel/S_{tag}", (1, M, cfg.lr_in_channels), 1.0))
+            ylens = (torch.LongTensor([M]) * 1.72).long()
+            out[f"lr_{tag}"] = mm.models["length_regulator"](S, ylens=ylens, n_quantizers=3, f0=None)[0].numpy()
+        # (d) one DiT forward, N=2 rows with different x_lens (exercises the key-padding mask and the WaveNet mask)
+        T = 37
+        x = torch.from_numpy(synth.uniform("golden/s2mel/dit/x", (2, cfg.in_channels, T), 1.0))
+        px = torch.from_numpy(synth.uniform("golden/s2mel/dit/prompt", (2, cfg.in_channels, T), 1.0))
+        px[..., 12:] = 0
+        st = torch.from_numpy(synth.uniform("golden/s2mel/dit/style", (2, cfg.style_dim), 1.0))
+        mu = torch.from_numpy(synth.uniform("golden/s2mel/dit/mu", (2, T, cfg.content_dim), 1.0))
+        tt = torch.tensor([0.35, 0.35])
+        out["dit"] = est(x, px, torch.LongTensor([T, T - 6]), tt, st, mu).numpy()
+        # (e) CFM Euler with CFG, B=1 (the reference's only mode), Tp=11 prompt frames + 23 generated, 3 steps
+        Tp, Tg = 11, 23
+        T = Tp + Tg
+        z = torch.from_numpy(synth.uniform("golden/s2mel/cfm/z", (1, cfg.in_channels, T), 1.7))
+        mu = torch.from_numpy(synth.uniform("golden/s2mel/cfm/mu", (1, T, cfg.content_dim), 1.0))
+        prompt = torch.from_numpy(synth.uniform("golden/s2mel/cfm/prompt", (1, cfg.in_channels, Tp), 1.0))
+        st = torch.from_numpy(synth.uniform("golden/s2mel/cfm/style", (1, cfg.style_dim), 1.0))
+        t_span = torch.linspace(0, 1, 3 + 1)
+        out["cfm"] = mm.models["cfm"].solve_euler(z.clone(), torch.LongTensor([T]), prompt, mu, st, None, t_span, 0.7).numpy()
+    np.savez_compressed(os.path.join(HERE, "s2mel.npz"), **out)
+    print("wrote s2mel.npz", {k: (v.shape, float(np.abs(v).max())) for k, v in out.items()})
+
+
+# ----------------------------------------------------------------------------------------------
 def make_gpt():
     """GPT-2 stack fixtures from the container's `transformers.GPT2Model` (the reference instantiates the
     same class from transformers==4.52.1 at model_v2.py:290-305) + HF's RepetitionPenaltyLogitsProcessor."""
