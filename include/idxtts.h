@@ -141,6 +141,36 @@ int idxtts_gpt_generate(idxtts_ctx* ctx, const float* inputs_embeds, const int* 
 int idxtts_gpt_latent(idxtts_ctx* ctx, const float* emb, int B, int S, int mel_start, int M, float* latent, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* ---- s2mel stage (reference: infer_v2.py:835-856; MyModel commons.py:390-420) -------------------------
+ * State-dict keys: "cfm.estimator.*", "length_regulator.*", "gpt_layer.{0,1,2}.*" (s2mel.pth['net'][...], weight-norm
+ * layers folded to plain ".weight"), "semantic_codec.quantizer.quantizers.0.{codebook.weight,out_project.weight,out_project.bias}",
+ * plus one constant table "rope_cache" [T][32][2] = precompute_freqs_cis (gpt_fast/model.py:336-345). */
+typedef struct idxtts_s2mel_config {
+  int hidden_dim, num_heads, depth;      /* DiT: 512, 8, 13 */
+  int in_channels, content_dim, style_dim;   /* 80, 512, 192 */
+  int wn_hidden, wn_layers, wn_kernel, wn_dilation_rate;   /* 512, 8, 5, 1 */
+  int lr_channels, lr_in_channels, lr_num_convs;           /* 512, 1024, 4 */
+  int gpt_dim; int gpt_layer_dims[3];                      /* 1280; 256,128,1024 */
+  int codebook_size, codebook_dim, codec_hidden;           /* 8192, 8, 1024 */
+  float norm_eps;                                          /* 1e-5 */
+} idxtts_s2mel_config;
+int idxtts_s2mel_create(const idxtts_s2mel_config* cfg, idxtts_ctx** out);
+/* cond = length_regulator(vq2emb(codes) + gpt_layer(latent)) (infer_v2.py:835-849).  latent [B][M][gpt_dim], codes int64
+ * [B][M] (device); code_lens / target_lens: HOST int32 [B] (target = floor(1.72 * code_len), infer_v2.py:844);
+ * cond_out [B][Tg][lr_channels], rows >= target_lens[b] are zero.  Statistics (GroupNorm) are per utterance. */
+size_t idxtts_s2mel_cond_workspace_bytes(const idxtts_ctx* ctx, int B, int M, int Tg);
+int idxtts_s2mel_prepare_cond(idxtts_ctx* ctx, const float* latent, const long long* codes, const int* code_lens,
+                              const int* target_lens, int B, int M, int Tg, float* cond_out, void* workspace,
+                              size_t workspace_bytes, void* stream);
+/* CFM Euler solve with classifier-free guidance = cfm.inference (flow_matching.py:31-115) with the noise given:
+ * mu [B][T][content_dim]; x_lens HOST [B]; prompt [B][in_channels][Tp_max] + prompt_lens HOST [B]; style [B][style_dim];
+ * z [B][in_channels][T] (the randn of flow_matching.py:52); t_emb device [n_steps][256] sinusoidal timestep features and
+ * dt HOST [n_steps] (both from torch.linspace as the reference does); out [B][in_channels][T] (caller slices off the prompt). */
+size_t idxtts_s2mel_cfm_workspace_bytes(const idxtts_ctx* ctx, int B, int T, int n_steps);
+int idxtts_s2mel_cfm(idxtts_ctx* ctx, const float* mu, const int* x_lens, const float* prompt, const int* prompt_lens, int Tp_max,
+                     const float* style, const float* z, const float* t_emb, const float* dt, int n_steps, float cfg_rate,
+                     float* out, int B, int T, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- per-kernel timing for the benchmark's roofline report ------------------------------------------
  * When enabled, every kernel launch is bracketed by HIP events on its own stream and the library
  * accumulates, per kernel family, the launch count, elapsed milliseconds and the ALGORITHMIC flops /

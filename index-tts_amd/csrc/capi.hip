@@ -7,6 +7,7 @@
 #include "conv1d.h"
 #include "ctx.h"
 #include "gpt.h"
+#include "s2mel.h"
 
 namespace idxtts {
 
@@ -284,6 +285,55 @@ int idxtts_gpt_latent(idxtts_ctx* ctx, const float* emb, int B, int S, int mel_s
   API_BEGIN
   GPT_MODEL(ctx);
   return m->latent(emb, B, S, mel_start, M, latent, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+  API_END
+}
+
+
+int idxtts_s2mel_create(const idxtts_s2mel_config* cfg, idxtts_ctx** out) {
+  API_BEGIN
+  IDX_CHECK(cfg && out, "null pointer");
+  std::unique_ptr<idxtts_ctx> ctx(new idxtts_ctx());
+  ctx->model.reset(new S2MelModel(*cfg));
+  *out = ctx.release();
+  return 0;
+  API_END
+}
+
+#define S2MEL_MODEL(ctx)                                      \
+  IDX_CHECK(ctx, "null ctx");                                 \
+  IDX_CHECK(ctx->finalized, "context not finalized");         \
+  auto* m = dynamic_cast<S2MelModel*>(ctx->model.get());      \
+  IDX_CHECK(m, "not an s2mel context")
+
+size_t idxtts_s2mel_cond_workspace_bytes(const idxtts_ctx* ctx, int B, int M, int Tg) {
+  if (!ctx || !ctx->finalized || B <= 0 || M <= 0 || Tg <= 0) return 0;
+  auto* m = dynamic_cast<const S2MelModel*>(ctx->model.get());
+  return m ? m->cond_workspace_bytes(B, M, Tg) : 0;
+}
+
+int idxtts_s2mel_prepare_cond(idxtts_ctx* ctx, const float* latent, const long long* codes, const int* code_lens,
+                              const int* target_lens, int B, int M, int Tg, float* cond_out, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  API_BEGIN
+  S2MEL_MODEL(ctx);
+  return m->prepare_cond(latent, codes, code_lens, target_lens, B, M, Tg, cond_out, workspace, workspace_bytes,
+                         static_cast<hipStream_t>(stream));
+  API_END
+}
+
+size_t idxtts_s2mel_cfm_workspace_bytes(const idxtts_ctx* ctx, int B, int T, int n_steps) {
+  if (!ctx || !ctx->finalized || B <= 0 || T <= 0 || n_steps <= 0) return 0;
+  auto* m = dynamic_cast<const S2MelModel*>(ctx->model.get());
+  return m ? m->cfm_workspace_bytes(B, T, n_steps) : 0;
+}
+
+int idxtts_s2mel_cfm(idxtts_ctx* ctx, const float* mu, const int* x_lens, const float* prompt, const int* prompt_lens, int Tp_max,
+                     const float* style, const float* z, const float* t_emb, const float* dt, int n_steps, float cfg_rate,
+                     float* out, int B, int T, void* workspace, size_t workspace_bytes, void* stream) {
+  API_BEGIN
+  S2MEL_MODEL(ctx);
+  return m->cfm(mu, x_lens, prompt, prompt_lens, Tp_max, style, z, t_emb, dt, n_steps, cfg_rate, out, B, T, workspace,
+                workspace_bytes, static_cast<hipStream_t>(stream));
   API_END
 }
 

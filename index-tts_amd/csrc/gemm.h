@@ -4,7 +4,7 @@
 
 namespace idxtts {
 
-enum GemmAct { ACT_NONE = 0, ACT_GELU_NEW = 1, ACT_SILU = 2, ACT_SWIGLU = 3, ACT_MISH = 4 };
+enum GemmAct { ACT_NONE = 0, ACT_GELU_NEW = 1, ACT_SILU = 2, ACT_SWIGLU = 3, ACT_MISH = 4, ACT_GATE = 5 /* tanh(a)*sigmoid(b), packed like SWIGLU */ };
 
 struct LinearWeights {      // device-resident, packed for the MFMA B operand
   const float* wp = nullptr;   // [ceil(N/32)][ceil(K/16)][g2][h2][j32][4]
@@ -27,6 +27,11 @@ struct GemmArgs {
   int M = 0;
   int act = ACT_NONE;
   float out_scale = 1.0f;
+  // token-major Conv1d over sequences of seq_len rows: y[b,t] = sum_tap W[:, tap*Kc + ci] x[b, t + tap*dil - pad_left, ci]
+  // (w.K = taps * Kc, Kc % 32 == 0).  pad_mode: 0 zero, 1 reflect (SConv1d, encodec.py:212-228).
+  int taps = 1, seq_len = 0, dil = 1, pad_left = 0, pad_mode = 0;
+  // optional output row mask: rows with (m % seq_len) >= row_len[m / seq_len] are written as 0 (x * x_mask)
+  const int* row_len = nullptr;
 };
 
 int gemm_tn_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t stream);

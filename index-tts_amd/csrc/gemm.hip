@@ -16,6 +16,7 @@
 // one 128-byte row segment hit 8 different bank groups.  W is packed once at context creation.
 // XCD-aware tile map: XCD x owns the m-tiles == x (mod 8) and walks them n-block-major, so the 32 CUs of
 // an XCD share one weight slice in their L2 while streaming different activation rows.
+#include <algorithm>
 #include <cmath>
 
 #include "gemm.h"
@@ -60,6 +61,8 @@ struct GemmKP {
   int mtiles, mt8; // 128-row tiles, ceil(mtiles/8)
   int act;
   float out_scale;
+  int taps, kc, seq_len, dil, pad_left, pad_mode;
+  const int* row_len;
 };
 
 constexpr int XBLK = 132;   // floats per padded [32 rows][4] sub-block (528 B)
@@ -92,7 +95,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmKP p) {
   const int wm = wave >> 1, wn = wave & 1;
 
   f32x4 xr[4], wr[4];
+  // conv mode: (sequence base row, position in sequence) of the 4 activation rows this thread stages
+  int seq_base[4], seq_t[4], seq_n[4];     // seq_n: true length of that sequence (reflect pad bounces at ITS end)
+  if (p.taps > 1) {
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const int m = bm * 128 + ((tid + 256 * l) >> 3);
+      const int sb = m / p.seq_len;
+      seq_base[l] = sb * p.seq_len;
+      seq_t[l] = m - sb * p.seq_len;
+      seq_n[l] = (p.row_len && m < p.M) ? min(p.row_len[sb], p.seq_len) : p.seq_len;
+    }
+  }
   auto load_tiles = [&](int kstep) {
+    int tap = 0, kk0 = kstep * 32;
+    if (p.taps > 1) { tap = kk0 / p.kc; kk0 -= tap * p.kc; }
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
       const int idx = tid + 256 * l;
@@ -100,7 +117,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmKP p) {
       const int row = idx >> 3, q8 = idx & 7;
       const int m = bm * 128 + row, k = kstep * 32 + q8 * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < p.M && k < p.K) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.ldx + k);
+      if (p.taps > 1) {
+        int t = seq_t[l] + tap * p.dil - p.pad_left;
+        if (p.pad_mode == 1) { t = t < 0 ? -t : t; t = t >= seq_n[l] ? 2 * (seq_n[l] - 1) - t : t; }
+        if (m < p.M && k < p.K && t >= 0 && t < seq_n[l])
+          v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(seq_base[l] + t) * p.ldx + kk0 + q8 * 4);
+      } else if (m < p.M && k < p.K) {
+        v = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.ldx + k);
+      }
       xr[l] = v;
       // weights: 4 KiB contiguous per 32-column tile (two 16-wide chunks)
       const int nt = idx >> 8, off = idx & 255;
@@ -163,7 +187,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmKP p) {
   }
 
   // ---- epilogue ----
-  if (p.act == ACT_SWIGLU) {
+  auto row_masked = [&](int m) -> bool {
+    if (!p.row_len) return false;
+    const int sb = m / p.seq_len;
+    return (m - sb * p.seq_len) >= p.row_len[sb];
+  };
+  if (p.act == ACT_SWIGLU || p.act == ACT_GATE) {
     // packed rows alternate [32 of w1 | 32 of w3]: acc[.][0] is the gate, acc[.][1] the linear branch
     const int n0 = bn * 128 + wn * 64 + j;            // packed column of the gate
     const int no = bn * 64 + wn * 32 + j;             // output column
@@ -176,8 +205,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmKP p) {
         const int m = bm * 128 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m >= p.M || !ok) continue;
         const float gte = acc[mt][0][r] + b0, lin = acc[mt][1][r] + b1;
-        float v = (gte / (1.0f + expf(-gte))) * lin * p.out_scale;
+        float v = p.act == ACT_SWIGLU ? (gte / (1.0f + expf(-gte))) * lin : tanhf(gte) * (1.0f / (1.0f + expf(-lin)));
+        v *= p.out_scale;
         if (p.res) v += p.res[(size_t)m * p.ldr + no];
+        if (row_masked(m)) v = 0.0f;
         p.y[(size_t)m * p.ldy + no] = v;
       }
     return;
@@ -195,6 +226,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmKP p) {
         if (m >= p.M) continue;
         float v = act_apply(acc[mt][nt][r] + bias, p.act) * p.out_scale;
         if (p.res) v += p.res[(size_t)m * p.ldr + n];
+        if (row_masked(m)) v = 0.0f;
         p.y[(size_t)m * p.ldy + n] = v;
       }
   }
@@ -206,7 +238,12 @@ int gemm_tn_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t strea
   IDX_CHECK(a.M > 0 && w.N > 0 && w.K > 0, "bad shape");
   IDX_CHECK((w.K & 3) == 0 && (a.ldx & 3) == 0, "K and ldx must be multiples of 4 (16-byte row segments)");
   IDX_CHECK((reinterpret_cast<uintptr_t>(a.x) & 15) == 0, "x must be 16-byte aligned");
-  if (a.act == ACT_SWIGLU) IDX_CHECK((w.N & 63) == 0, "SWIGLU needs N (= 2*hidden) to be a multiple of 64");
+  if (a.act == ACT_SWIGLU || a.act == ACT_GATE) IDX_CHECK((w.N & 63) == 0, "paired activations need N (= 2*hidden) to be a multiple of 64");
+  if (a.taps > 1) {
+    IDX_CHECK(a.seq_len > 0 && a.M % a.seq_len == 0 && w.K % a.taps == 0 && ((w.K / a.taps) & 31) == 0, "conv mode: K/taps must be a multiple of 32 and M a multiple of seq_len");
+    if (a.pad_mode == 1) IDX_CHECK(a.seq_len > (a.taps - 1) * a.dil, "reflect pad needs seq_len > halo");
+  }
+  if (a.row_len) IDX_CHECK(a.seq_len > 0, "row_len needs seq_len");
   GemmKP p;
   p.x = a.x; p.wp = w.wp; p.bias = w.bias; p.res = a.res; p.y = a.y;
   p.M = a.M; p.N = w.N; p.K = w.K; p.ldx = a.ldx; p.ldy = a.ldy; p.ldr = a.ldr;
@@ -214,6 +251,8 @@ int gemm_tn_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t strea
   p.mtiles = cdiv(a.M, 128);
   p.mt8 = cdiv(p.mtiles, 8);
   p.act = a.act; p.out_scale = a.out_scale;
+  p.taps = a.taps; p.kc = w.K / std::max(1, a.taps); p.seq_len = a.seq_len > 0 ? a.seq_len : 1; p.dil = a.dil; p.pad_left = a.pad_left;
+  p.pad_mode = a.pad_mode; p.row_len = a.row_len;
   const int nblocks = cdiv(w.N, 128);
   const int64_t grid = (int64_t)8 * nblocks * p.mt8;
   IDX_CHECK(grid < (1ll << 31), "grid size");

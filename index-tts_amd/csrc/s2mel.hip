@@ -1,0 +1,521 @@
+// IndexTTS-2 semantic-to-mel stage on MI355X: gpt_layer + vq2emb + length regulator, and the CFM Euler
+// solver over the DiT (13 adaLN-RMSNorm/rotary/SwiGLU blocks with U-ViT skips) + WaveNet estimator.
+//
+// Reference: infer_v2.py:835-856 (caller), commons.py:390-420 (MyModel), length_regulator.py:90-141,
+// flow_matching.py:31-115, diffusion_transformer.py:186-257, gpt_fast/model.py:121-360, wavenet.py:138-166.
+//
+// Layout: everything is token-major [rows = (stacked batch, frame)][channels] so that every linear AND every
+// convolution (WaveNet k=5 reflect-pad, length-regulator k=3) is the same fp32-MFMA GEMM (gemm.hip; the conv
+// taps are shifted row reads inside the tile loader, no im2col, no transposes between the DiT and the WaveNet).
+// Only the 80-channel ODE state x stays channels-first [B][80][T] (the boundary layout, flow_matching.py:52).
+//
+// What is hoisted out of the Euler loop (all of it depends on t only, not on the data):
+//   timestep MLPs, all 27 adaLN modulation vectors, the FinalLayer shift/scale and the WaveNet conditioning
+//   bias g_l (folded with the in_layer bias) are computed ONCE per call for all steps by five small GEMMs
+//   with M = n_steps; cond_projection(mu) is computed once per call.  The reference recomputes all of them
+//   in every step (diffusion_transformer.py:212-213, wavenet.py:142-152).
+// CFG: the [cond | null] stacking of flow_matching.py:89-93 is kept (2B rows per step).
+#include <cmath>
+#include <cstring>
+
+#include "s2mel.h"
+
+namespace idxtts {
+
+S2MelModel::S2MelModel(const idxtts_s2mel_config& c) : cfg(c) {}
+
+bool S2MelModel::accepts(const std::string& name) const {
+  static const char* prefixes[] = {"cfm.estimator.", "length_regulator.", "gpt_layer.", "semantic_codec.", "rope_cache"};
+  for (const char* p : prefixes)
+    if (name.rfind(p, 0) == 0) return true;
+  return false;
+}
+
+namespace {
+
+int need(std::map<std::string, HostTensor>& t, const std::string& key, std::vector<int64_t> shape, HostTensor** out) {
+  auto it = t.find(key);
+  if (it == t.end()) IDX_FAIL("missing tensor '" + key + "'");
+  if (it->second.shape != shape) IDX_FAIL("tensor '" + key + "' has the wrong shape");
+  *out = &it->second;
+  return 0;
+}
+
+int up(DeviceArena& arena, const std::vector<float>& v, const float** out) {
+  float* d = nullptr;
+  if (arena.upload(v.data(), v.size(), &d)) return 1;
+  *out = d;
+  return 0;
+}
+
+// rows [N][K] host matrix (+ optional bias) -> packed LinearWeights
+int make_linear(DeviceArena& arena, const std::vector<float>& w, const std::vector<float>* bias, int N, int K, LinearWeights* out) {
+  std::vector<float> packed(linear_packed_floats(N, K));
+  pack_linear(packed.data(), w.data(), N, K);
+  if (up(arena, packed, &out->wp)) return 1;
+  out->N = N; out->K = K;
+  if (bias && up(arena, *bias, &out->bias)) return 1;
+  return 0;
+}
+
+int linear_from(std::map<std::string, HostTensor>& t, DeviceArena& arena, const std::string& prefix, int N, int K, bool bias,
+                LinearWeights* out) {
+  HostTensor *w = nullptr, *b = nullptr;
+  if (need(t, prefix + ".weight", {N, K}, &w)) return 1;
+  if (bias && need(t, prefix + ".bias", {N}, &b)) return 1;
+  return make_linear(arena, w->data, b ? &b->data : nullptr, N, K, out);
+}
+
+// columns [k0, k1) of a [N][K] matrix
+std::vector<float> col_slice(const std::vector<float>& w, int N, int K, int k0, int k1) {
+  std::vector<float> o((size_t)N * (k1 - k0));
+  for (int n = 0; n < N; ++n) std::memcpy(&o[(size_t)n * (k1 - k0)], &w[(size_t)n * K + k0], (k1 - k0) * sizeof(float));
+  return o;
+}
+
+// interleave two [H][K] blocks as [32 of a | 32 of b] groups (SwiGLU / tanh-sigmoid gate packing)
+std::vector<float> pair_pack(const float* a, const float* b, int H, int K) {
+  std::vector<float> o((size_t)2 * H * K);
+  for (int blk = 0; blk < H / 32; ++blk) {
+    std::memcpy(&o[(size_t)(blk * 64) * K], a + (size_t)blk * 32 * K, (size_t)32 * K * sizeof(float));
+    std::memcpy(&o[(size_t)(blk * 64 + 32) * K], b + (size_t)blk * 32 * K, (size_t)32 * K * sizeof(float));
+  }
+  return o;
+}
+
+// torch Conv1d weight [Cout][Cin][k] -> [Cout][k*Cin] (tap-major K, the order the conv-mode tile loader walks)
+std::vector<float> conv_to_rows(const std::vector<float>& w, int Cout, int Cin, int k) {
+  std::vector<float> o((size_t)Cout * Cin * k);
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int kk = 0; kk < k; ++kk) o[((size_t)co * k + kk) * Cin + ci] = w[((size_t)co * Cin + ci) * k + kk];
+  return o;
+}
+
+}  // namespace
+
+int S2MelModel::finalize(std::map<std::string, HostTensor>& t, DeviceArena& arena) {
+  const int D = cfg.hidden_dim, C = cfg.in_channels, Wh = cfg.wn_hidden, depth = cfg.depth;
+  IDX_CHECK(D == cfg.num_heads * 64, "head_dim must be 64");
+  IDX_CHECK(Wh == D, "the reference's FinalLayer requires wavenet.hidden_dim == DiT.hidden_dim");
+  IDX_CHECK((D & 31) == 0 && (Wh & 31) == 0 && (cfg.lr_channels & 31) == 0, "channel counts must be multiples of 32");
+  {
+    const int nh = (int)(2 * (4 * D) / 3);
+    ffn = (nh % 256 == 0) ? nh : nh + 256 - (nh % 256);
+  }
+  const std::string e = "cfm.estimator";
+  blocks.resize(depth);
+  std::vector<float> mod_w, mod_b;
+  auto append_mod = [&](const std::string& name) -> int {
+    HostTensor *w = nullptr, *b = nullptr;
+    if (need(t, name + ".project_layer.weight", {2 * D, D}, &w) || need(t, name + ".project_layer.bias", {2 * D}, &b)) return 1;
+    mod_w.insert(mod_w.end(), w->data.begin(), w->data.end());
+    mod_b.insert(mod_b.end(), b->data.begin(), b->data.end());
+    return 0;
+  };
+  for (int i = 0; i < depth; ++i) {
+    DiTBlock& B = blocks[i];
+    const std::string p = e + ".transformer.layers." + std::to_string(i);
+    if (linear_from(t, arena, p + ".attention.wqkv", 3 * D, D, false, &B.wqkv)) return 1;
+    if (linear_from(t, arena, p + ".attention.wo", D, D, false, &B.wo)) return 1;
+    HostTensor *w1 = nullptr, *w3 = nullptr;
+    if (need(t, p + ".feed_forward.w1.weight", {ffn, D}, &w1) || need(t, p + ".feed_forward.w3.weight", {ffn, D}, &w3)) return 1;
+    if (make_linear(arena, pair_pack(w1->data.data(), w3->data.data(), ffn, D), nullptr, 2 * ffn, D, &B.w13)) return 1;
+    if (linear_from(t, arena, p + ".feed_forward.w2", D, ffn, false, &B.w2)) return 1;
+    HostTensor *g = nullptr;
+    if (need(t, p + ".attention_norm.norm.weight", {D}, &g) || up(arena, g->data, &B.attn_g)) return 1;
+    if (need(t, p + ".ffn_norm.norm.weight", {D}, &g) || up(arena, g->data, &B.ffn_g)) return 1;
+    if (append_mod(p + ".attention_norm") || append_mod(p + ".ffn_norm")) return 1;
+    if (i > depth / 2) {
+      HostTensor *sw = nullptr, *sb = nullptr;
+      if (need(t, p + ".skip_in_linear.weight", {D, 2 * D}, &sw) || need(t, p + ".skip_in_linear.bias", {D}, &sb)) return 1;
+      if (make_linear(arena, col_slice(sw->data, D, 2 * D, 0, D), &sb->data, D, D, &B.skip_a)) return 1;
+      if (make_linear(arena, col_slice(sw->data, D, 2 * D, D, 2 * D), nullptr, D, D, &B.skip_b)) return 1;
+    }
+  }
+  {
+    HostTensor* g = nullptr;
+    if (need(t, e + ".transformer.norm.norm.weight", {D}, &g) || up(arena, g->data, &final_g)) return 1;
+    if (append_mod(e + ".transformer.norm")) return 1;
+    if (make_linear(arena, mod_w, &mod_b, (2 * depth + 1) * 2 * D, D, &mod_all)) return 1;
+  }
+  const int Win = 2 * C + D + cfg.style_dim;
+  if (linear_from(t, arena, e + ".cond_projection", D, cfg.content_dim, true, &cond_proj)) return 1;
+  if (linear_from(t, arena, e + ".cond_x_merge_linear", D, Win, true, &merge)) return 1;
+  if (linear_from(t, arena, e + ".t_embedder.mlp.0", D, 256, true, &temb0) || linear_from(t, arena, e + ".t_embedder.mlp.2", D, D, true, &temb2)) return 1;
+  if (linear_from(t, arena, e + ".t_embedder2.mlp.0", Wh, 256, true, &t2emb0) || linear_from(t, arena, e + ".t_embedder2.mlp.2", Wh, Wh, true, &t2emb2)) return 1;
+  {
+    HostTensor *sw = nullptr, *sb = nullptr;
+    if (need(t, e + ".skip_linear.weight", {D, D + C}, &sw) || need(t, e + ".skip_linear.bias", {D}, &sb)) return 1;
+    if (make_linear(arena, col_slice(sw->data, D, D + C, 0, D), &sb->data, D, D, &skiplin_a)) return 1;
+    if (make_linear(arena, col_slice(sw->data, D, D + C, D, D + C), nullptr, D, C, &skiplin_b)) return 1;
+  }
+  if (linear_from(t, arena, e + ".conv1", Wh, D, true, &conv1)) return 1;
+  if (linear_from(t, arena, e + ".res_projection", Wh, D, true, &res_proj)) return 1;
+  if (linear_from(t, arena, e + ".final_layer.linear", Wh, Wh, true, &final_lin)) return 1;
+  if (linear_from(t, arena, e + ".final_layer.adaLN_modulation.1", 2 * Wh, Wh, true, &final_mod)) return 1;
+  {
+    HostTensor *w = nullptr, *b = nullptr;
+    if (need(t, e + ".conv2.weight", {C, Wh, 1}, &w) || need(t, e + ".conv2.bias", {C}, &b)) return 1;
+    if (make_linear(arena, w->data, &b->data, C, Wh, &conv2)) return 1;
+  }
+  // ---- WaveNet ----
+  const int L = cfg.wn_layers, k = cfg.wn_kernel;
+  wn.resize(L);
+  {
+    HostTensor *cw = nullptr, *cb = nullptr;
+    if (need(t, e + ".wavenet.cond_layer.conv.conv.weight", {2 * Wh * L, Wh, 1}, &cw) ||
+        need(t, e + ".wavenet.cond_layer.conv.conv.bias", {2 * Wh * L}, &cb)) return 1;
+    std::vector<float> cw_perm, cb_perm;
+    for (int l = 0; l < L; ++l) {
+      WNLayer& W = wn[l];
+      const std::string p = e + ".wavenet.in_layers." + std::to_string(l) + ".conv.conv";
+      HostTensor *iw = nullptr, *ib = nullptr;
+      if (need(t, p + ".weight", {2 * Wh, Wh, k}, &iw) || need(t, p + ".bias", {2 * Wh}, &ib)) return 1;
+      const std::vector<float> rows = conv_to_rows(iw->data, 2 * Wh, Wh, k);
+      if (make_linear(arena, pair_pack(rows.data(), rows.data() + (size_t)Wh * k * Wh, Wh, k * Wh), nullptr, 2 * Wh, k * Wh, &W.in_gate)) return 1;
+      // cond_layer slice of this layer, same gate packing; its bias absorbs the in_layer bias
+      const float* cwl = cw->data.data() + (size_t)l * 2 * Wh * Wh;
+      const std::vector<float> cwp = pair_pack(cwl, cwl + (size_t)Wh * Wh, Wh, Wh);
+      cw_perm.insert(cw_perm.end(), cwp.begin(), cwp.end());
+      std::vector<float> bsum(2 * Wh);
+      for (int c = 0; c < 2 * Wh; ++c) bsum[c] = cb->data[(size_t)l * 2 * Wh + c] + ib->data[c];
+      const std::vector<float> bp = pair_pack(bsum.data(), bsum.data() + Wh, Wh, 1);
+      cb_perm.insert(cb_perm.end(), bp.begin(), bp.end());
+      const std::string r = e + ".wavenet.res_skip_layers." + std::to_string(l) + ".conv.conv";
+      const int rc = l < L - 1 ? 2 * Wh : Wh;
+      HostTensor *rw = nullptr, *rb = nullptr;
+      if (need(t, r + ".weight", {rc, Wh, 1}, &rw) || need(t, r + ".bias", {rc}, &rb)) return 1;
+      if (l < L - 1) {
+        std::vector<float> w_res(rw->data.begin(), rw->data.begin() + (size_t)Wh * Wh), b_res(rb->data.begin(), rb->data.begin() + Wh);
+        std::vector<float> w_skip(rw->data.begin() + (size_t)Wh * Wh, rw->data.end()), b_skip(rb->data.begin() + Wh, rb->data.end());
+        if (make_linear(arena, w_res, &b_res, Wh, Wh, &W.res) || make_linear(arena, w_skip, &b_skip, Wh, Wh, &W.skip)) return 1;
+      } else {
+        W.has_res = false;
+        if (make_linear(arena, rw->data, &rb->data, Wh, Wh, &W.skip)) return 1;
+      }
+    }
+    if (make_linear(arena, cw_perm, &cb_perm, 2 * Wh * L, Wh, &wn_cond)) return 1;
+  }
+  // ---- length regulator, gpt_layer, codec table ----
+  const int LC = cfg.lr_channels;
+  if (linear_from(t, arena, "length_regulator.content_in_proj", LC, cfg.lr_in_channels, true, &lr_in)) return 1;
+  lr_conv.resize(cfg.lr_num_convs);
+  lr_gn_g.resize(cfg.lr_num_convs);
+  lr_gn_b.resize(cfg.lr_num_convs);
+  for (int n = 0; n < cfg.lr_num_convs; ++n) {
+    HostTensor *w = nullptr, *b = nullptr, *g = nullptr, *bb = nullptr;
+    const std::string p = "length_regulator.model." + std::to_string(3 * n);
+    if (need(t, p + ".weight", {LC, LC, 3}, &w) || need(t, p + ".bias", {LC}, &b)) return 1;
+    if (make_linear(arena, conv_to_rows(w->data, LC, LC, 3), &b->data, LC, 3 * LC, &lr_conv[n])) return 1;
+    const std::string q = "length_regulator.model." + std::to_string(3 * n + 1);
+    if (need(t, q + ".weight", {LC}, &g) || need(t, q + ".bias", {LC}, &bb)) return 1;
+    if (up(arena, g->data, &lr_gn_g[n]) || up(arena, bb->data, &lr_gn_b[n])) return 1;
+  }
+  {
+    HostTensor *w = nullptr, *b = nullptr;
+    const std::string p = "length_regulator.model." + std::to_string(3 * cfg.lr_num_convs);
+    if (need(t, p + ".weight", {LC, LC, 1}, &w) || need(t, p + ".bias", {LC}, &b)) return 1;
+    if (make_linear(arena, w->data, &b->data, LC, LC, &lr_out)) return 1;
+  }
+  {
+    const int dims[4] = {cfg.gpt_dim, cfg.gpt_layer_dims[0], cfg.gpt_layer_dims[1], cfg.gpt_layer_dims[2]};
+    for (int n = 0; n < 3; ++n)
+      if (linear_from(t, arena, "gpt_layer." + std::to_string(n), dims[n + 1], dims[n], true, &gl[n])) return 1;
+    IDX_CHECK(dims[3] == cfg.codec_hidden && cfg.codec_hidden == cfg.lr_in_channels, "gpt_layer / codec / length-regulator widths");
+  }
+  {
+    // vq2emb table: out_project(codebook[v]) for every v (factorized_vector_quantize.py:123-127)
+    HostTensor *cb = nullptr, *ow = nullptr, *ob = nullptr;
+    const std::string q = "semantic_codec.quantizer.quantizers.0";
+    if (need(t, q + ".codebook.weight", {cfg.codebook_size, cfg.codebook_dim}, &cb) ||
+        need(t, q + ".out_project.weight", {cfg.codec_hidden, cfg.codebook_dim, 1}, &ow) ||
+        need(t, q + ".out_project.bias", {cfg.codec_hidden}, &ob)) return 1;
+    std::vector<float> table((size_t)cfg.codebook_size * cfg.codec_hidden);
+    for (int v = 0; v < cfg.codebook_size; ++v)
+      for (int h = 0; h < cfg.codec_hidden; ++h) {
+        float acc = 0.0f;
+        for (int c = 0; c < cfg.codebook_dim; ++c) acc = std::fmaf(cb->data[(size_t)v * cfg.codebook_dim + c], ow->data[(size_t)h * cfg.codebook_dim + c], acc);
+        table[(size_t)v * cfg.codec_hidden + h] = acc + ob->data[h];
+      }
+    if (up(arena, table, &vq_table)) return 1;
+  }
+  {
+    auto it = t.find("rope_cache");
+    if (it == t.end()) IDX_FAIL("missing tensor 'rope_cache' ([T][32][2] cos/sin table, precompute_freqs_cis)");
+    IDX_CHECK(it->second.shape.size() == 3 && it->second.shape[1] == 32 && it->second.shape[2] == 2, "rope_cache must be [T][32][2]");
+    rope_len = (int)it->second.shape[0];
+    if (up(arena, it->second.data, &rope)) return 1;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct Carver2 {
+  char* base; size_t off = 0;
+  explicit Carver2(void* b) : base(static_cast<char*>(b)) {}
+  template <typename T> T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+struct CfmBuffers {
+  float *x_in, *ha, *hb, *hmid, *hn, *qkv, *att, *ff, *xres, *wn_x, *wn_acts, *wn_out, *vout, *condp, *xstate;
+  std::vector<float*> skips;
+  float *t1, *t1s, *mods, *fmod, *t2, *wnb, *tmp_steps;
+  int *lens2, *plen;
+  size_t bytes;
+};
+
+static CfmBuffers carve_cfm(const S2MelModel& m, void* ws, int B, int T, int n_steps) {
+  const auto& c = m.cfg;
+  const int D = c.hidden_dim, C = c.in_channels, Wh = c.wn_hidden;
+  const size_t M2 = (size_t)2 * B * T;
+  const int Win = 2 * C + D + c.style_dim;
+  CfmBuffers b;
+  Carver2 k(ws);
+  b.x_in = k.take<float>(M2 * Win);
+  b.ha = k.take<float>(M2 * D);
+  b.hb = k.take<float>(M2 * D);
+  b.hmid = k.take<float>(M2 * D);
+  b.hn = k.take<float>(M2 * D);
+  b.qkv = k.take<float>(M2 * 3 * D);
+  b.att = k.take<float>(M2 * D);
+  b.ff = k.take<float>(M2 * m.ffn);
+  b.xres = k.take<float>(M2 * D);
+  b.wn_x = k.take<float>(M2 * Wh);
+  b.wn_acts = k.take<float>(M2 * Wh);
+  b.wn_out = k.take<float>(M2 * Wh);
+  b.vout = k.take<float>(M2 * C);
+  b.condp = k.take<float>((size_t)B * T * D);
+  b.xstate = k.take<float>((size_t)B * C * T);
+  for (int i = 0; i < c.depth / 2; ++i) b.skips.push_back(k.take<float>(M2 * D));
+  b.t1 = k.take<float>((size_t)n_steps * D);
+  b.t1s = k.take<float>((size_t)n_steps * D);
+  b.tmp_steps = k.take<float>((size_t)n_steps * std::max(D, Wh));
+  b.mods = k.take<float>((size_t)n_steps * (2 * c.depth + 1) * 2 * D);
+  b.fmod = k.take<float>((size_t)n_steps * 2 * Wh);
+  b.t2 = k.take<float>((size_t)n_steps * Wh);
+  b.wnb = k.take<float>((size_t)n_steps * c.wn_layers * 2 * Wh);
+  b.lens2 = k.take<int>(2 * B);
+  b.plen = k.take<int>(B);
+  b.bytes = (k.off + 255) & ~(size_t)255;
+  return b;
+}
+
+size_t S2MelModel::cfm_workspace_bytes(int B, int T, int n_steps) const { return carve_cfm(*this, nullptr, B, T, n_steps).bytes; }
+
+static int gemm(const LinearWeights& w, const float* x, int ldx, float* y, int ldy, int M, hipStream_t st, int act = ACT_NONE,
+                const float* res = nullptr, int ldr = 0) {
+  GemmArgs a;
+  a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.M = M; a.act = act; a.res = res; a.ldr = ldr;
+  return gemm_tn_forward(w, a, st);
+}
+
+static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipStream_t st) {
+  const auto& c = m.cfg;
+  const int D = c.hidden_dim, C = c.in_channels, Wh = c.wn_hidden, depth = c.depth, half = depth / 2;
+  const int M = N2 * T, Win = 2 * C + D + c.style_dim;
+  const float* mods = w.mods + (size_t)step * (2 * depth + 1) * 2 * D;
+  auto ada = [&](const float* x, const float* g, int mod_idx) {
+    RowsNormArgs n;
+    n.x_in = x; n.ld_in = D; n.y = w.hn; n.ld_y = D; n.M = M; n.d = D; n.mode = NORM_ADA_RMS; n.eps = c.norm_eps; n.g1 = g;
+    n.mod_a = mods + (size_t)mod_idx * 2 * D; n.mod_b = n.mod_a + D; n.ld_mod = 0; n.rows_per_batch = 0;
+    return rows_norm_forward(n, st);
+  };
+  if (gemm(m.merge, w.x_in, Win, w.ha, D, M, st)) return 1;
+  float* h = w.ha;
+  int pushed = 0;
+  for (int i = 0; i < depth; ++i) {
+    DiTBlock& B = m.blocks[i];
+    if (i > half) {     // U-ViT receive: skip_in_linear(cat[x, skip]) as two GEMMs (model.py:233-234)
+      float* skip = w.skips[--pushed];
+      if (gemm(B.skip_a, h, D, w.hmid, D, M, st)) return 1;
+      float* dst = (h == w.ha) ? w.hb : w.ha;
+      if (gemm(B.skip_b, skip, D, dst, D, M, st, ACT_NONE, w.hmid, D)) return 1;
+      h = dst;
+    }
+    if (ada(h, B.attn_g, 2 * i)) return 1;
+    if (gemm(B.wqkv, w.hn, D, w.qkv, 3 * D, M, st)) return 1;
+    if (rotary_qk(w.qkv, M, c.num_heads, T, m.rope, st)) return 1;
+    AttnArgs a;
+    a.q = w.qkv; a.k = w.qkv + D; a.v = w.qkv + 2 * D; a.o = w.att;
+    a.q_bs = a.k_bs = a.v_bs = (long)T * 3 * D; a.o_bs = (long)T * D;
+    a.q_ts = a.k_ts = a.v_ts = 3 * D; a.o_ts = D;
+    a.B = N2; a.H = c.num_heads; a.Sq = T; a.Sk = T; a.causal = 0; a.kend = w.lens2; a.scale = 0.125f;
+    if (flash_attn_forward(a, st)) return 1;
+    if (gemm(B.wo, w.att, D, w.hmid, D, M, st, ACT_NONE, h, D)) return 1;           // h + attention(...)
+    if (ada(w.hmid, B.ffn_g, 2 * i + 1)) return 1;
+    if (gemm(B.w13, w.hn, D, w.ff, m.ffn, M, st, ACT_SWIGLU)) return 1;
+    float* dst = (i < half) ? w.skips[pushed] : ((h == w.ha) ? w.hb : w.ha);
+    if (gemm(B.w2, w.ff, m.ffn, dst, D, M, st, ACT_NONE, w.hmid, D)) return 1;      // out = h + ffn
+    if (i < half) ++pushed;
+    h = dst;
+  }
+  if (ada(h, m.final_g, 2 * depth)) return 1;
+  // long skip: skip_linear(cat[x_res, x]) (diffusion_transformer.py:243-244); x rows live in x_in[:, :C]
+  if (gemm(m.skiplin_a, w.hn, D, w.hmid, D, M, st)) return 1;
+  if (gemm(m.skiplin_b, w.x_in, Win, w.xres, D, M, st, ACT_NONE, w.hmid, D)) return 1;
+  if (gemm(m.conv1, w.xres, D, w.wn_x, Wh, M, st)) return 1;
+  // WaveNet (wavenet.py:138-166)
+  const int L = c.wn_layers, k = c.wn_kernel;
+  for (int l = 0; l < L; ++l) {
+    WNLayer& W = m.wn[l];
+    int dil = 1;
+    for (int q = 0; q < l; ++q) dil *= c.wn_dilation_rate;
+    LinearWeights in = W.in_gate;
+    in.bias = w.wnb + ((size_t)step * L + l) * 2 * Wh;     // in_layer bias + g_l of this step, gate-packed
+    GemmArgs g;
+    g.x = w.wn_x; g.ldx = Wh; g.y = w.wn_acts; g.ldy = Wh; g.M = M; g.act = ACT_GATE;
+    g.taps = k; g.seq_len = T; g.dil = dil; g.pad_left = (k - 1) / 2 * dil; g.pad_mode = 1; g.row_len = w.lens2;
+    if (gemm_tn_forward(in, g, st)) return 1;
+    if (W.has_res) {   // x = (x + res) * mask
+      GemmArgs r;
+      r.x = w.wn_acts; r.ldx = Wh; r.y = w.wn_x; r.ldy = Wh; r.res = w.wn_x; r.ldr = Wh; r.M = M; r.seq_len = T; r.row_len = w.lens2;
+      if (gemm_tn_forward(W.res, r, st)) return 1;
+    }
+    GemmArgs s;        // output += skip ; the last layer's epilogue applies "* x_mask" to the finished sum
+    s.x = w.wn_acts; s.ldx = Wh; s.y = w.wn_out; s.ldy = Wh; s.M = M;
+    if (l > 0) { s.res = w.wn_out; s.ldr = Wh; }
+    if (l == L - 1) { s.seq_len = T; s.row_len = w.lens2; }
+    if (gemm_tn_forward(W.skip, s, st)) return 1;
+  }
+  if (gemm(m.res_proj, w.xres, D, w.hmid, Wh, M, st, ACT_NONE, w.wn_out, Wh)) return 1;
+  {
+    RowsNormArgs n;     // FinalLayer (diffusion_transformer.py:96-101)
+    n.x_in = w.hmid; n.ld_in = Wh; n.y = w.hn; n.ld_y = Wh; n.M = M; n.d = Wh; n.mode = NORM_MOD_LN; n.eps = 1e-6f;
+    n.mod_a = w.fmod + (size_t)step * 2 * Wh; n.mod_b = n.mod_a + Wh; n.ld_mod = 0; n.rows_per_batch = 0;
+    if (rows_norm_forward(n, st)) return 1;
+  }
+  if (gemm(m.final_lin, w.hn, Wh, w.att, Wh, M, st)) return 1;
+  return gemm(m.conv2, w.att, Wh, w.vout, C, M, st);
+}
+
+int S2MelModel::cfm(const float* mu, const int* x_lens_host, const float* prompt, const int* prompt_lens_host, int Tp_max,
+                    const float* style, const float* z, const float* t_emb, const float* dt_host, int n_steps, float cfg_rate,
+                    float* out, int B, int T, void* ws, size_t ws_bytes, hipStream_t st) {
+  IDX_CHECK(mu && x_lens_host && prompt && prompt_lens_host && style && z && t_emb && dt_host && out, "null pointer");
+  IDX_CHECK(B > 0 && T > 0 && n_steps > 0 && Tp_max > 0, "shape");
+  IDX_CHECK(cfg_rate > 0.0f, "the stacked-CFG path needs inference_cfg_rate > 0 (reference default 0.7)");
+  IDX_CHECK(T <= rope_len, "sequence longer than the rope cache");
+  IDX_CHECK(ws && ws_bytes >= cfm_workspace_bytes(B, T, n_steps), "workspace too small");
+  const int D = cfg.hidden_dim, C = cfg.in_channels, Wh = cfg.wn_hidden, depth = cfg.depth, L = cfg.wn_layers;
+  CfmBuffers w = carve_cfm(*this, ws, B, T, n_steps);
+  std::vector<int> lens2(2 * B), plen(B);
+  for (int b = 0; b < B; ++b) {
+    IDX_CHECK(x_lens_host[b] > 0 && x_lens_host[b] <= T && prompt_lens_host[b] >= 0 && prompt_lens_host[b] <= std::min(Tp_max, x_lens_host[b]), "lengths");
+    lens2[b] = lens2[B + b] = x_lens_host[b];
+    plen[b] = prompt_lens_host[b];
+  }
+  IDX_HIP(hipMemcpyAsync(w.lens2, lens2.data(), 2 * B * sizeof(int), hipMemcpyHostToDevice, st));
+  IDX_HIP(hipMemcpyAsync(w.plen, plen.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
+  IDX_HIP(hipStreamSynchronize(st));
+  // ---- per-call constants: every t-dependent vector for all steps at once (M = n_steps GEMMs) ----
+  if (gemm(temb0, t_emb, 256, w.tmp_steps, D, n_steps, st, ACT_SILU) || gemm(temb2, w.tmp_steps, D, w.t1, D, n_steps, st)) return 1;
+  if (gemm(mod_all, w.t1, D, w.mods, (2 * depth + 1) * 2 * D, n_steps, st)) return 1;
+  if (silu_rows(w.t1s, w.t1, (size_t)n_steps * D, st) || gemm(final_mod, w.t1s, Wh, w.fmod, 2 * Wh, n_steps, st)) return 1;
+  if (gemm(t2emb0, t_emb, 256, w.tmp_steps, Wh, n_steps, st, ACT_SILU) || gemm(t2emb2, w.tmp_steps, Wh, w.t2, Wh, n_steps, st)) return 1;
+  if (gemm(wn_cond, w.t2, Wh, w.wnb, L * 2 * Wh, n_steps, st)) return 1;
+  if (gemm(cond_proj, mu, cfg.content_dim, w.condp, D, B * T, st)) return 1;
+  if (cfm_init_state(w.xstate, z, w.plen, B, C, T, st)) return 1;       // x[..., :prompt_len] = 0 (flow_matching.py:82)
+  for (int s = 0; s < n_steps; ++s) {
+    CfmPackArgs pk;
+    pk.x_in = w.x_in; pk.ld = 2 * C + D + cfg.style_dim; pk.x = w.xstate; pk.prompt = prompt; pk.prompt_len = w.plen;
+    pk.cond = w.condp; pk.cond_null = cond_proj.bias; pk.style = style;
+    pk.B = B; pk.T = T; pk.C = C; pk.D = D; pk.S = cfg.style_dim; pk.Tp_max = Tp_max;
+    if (cfm_pack(pk, st)) return 1;
+    if (dit_eval(*this, w, 2 * B, T, s, st)) return 1;
+    CfmEulerArgs eu;
+    eu.x = w.xstate; eu.v = w.vout; eu.ldv = C; eu.prompt_len = w.plen; eu.B = B; eu.T = T; eu.C = C; eu.dt = dt_host[s]; eu.cfg_rate = cfg_rate;
+    if (cfm_euler(eu, st)) return 1;
+  }
+  IDX_HIP(hipMemcpyAsync(out, w.xstate, (size_t)B * C * T * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct CondBuffers { float *a, *b, *s, *stats; int *idx_code, *idx_row, *idx_interp, *tlen; size_t bytes; };
+
+static CondBuffers carve_cond(const S2MelModel& m, void* ws, int B, int M, int Tg) {
+  const auto& c = m.cfg;
+  CondBuffers b;
+  Carver2 k(ws);
+  const size_t rows = (size_t)B * std::max(M, Tg);
+  const int wide = std::max(std::max(c.codec_hidden, c.lr_channels), std::max(c.gpt_layer_dims[0], c.gpt_layer_dims[1]));
+  b.a = k.take<float>(rows * wide);
+  b.b = k.take<float>(rows * wide);
+  b.s = k.take<float>(rows * wide);
+  b.stats = k.take<float>(2 * B);
+  b.idx_code = k.take<int>((size_t)B * M);
+  b.idx_row = k.take<int>((size_t)B * M);
+  b.idx_interp = k.take<int>((size_t)B * Tg);
+  b.tlen = k.take<int>(B);
+  b.bytes = (k.off + 255) & ~(size_t)255;
+  return b;
+}
+
+size_t S2MelModel::cond_workspace_bytes(int B, int M, int Tg) const { return carve_cond(*this, nullptr, B, M, Tg).bytes; }
+
+int S2MelModel::prepare_cond(const float* latent, const long long* codes, const int* code_lens_host, const int* target_lens_host,
+                             int B, int M, int Tg, float* cond_out, void* ws, size_t ws_bytes, hipStream_t st) {
+  IDX_CHECK(latent && codes && code_lens_host && target_lens_host && cond_out, "null pointer");
+  IDX_CHECK(B > 0 && M > 0 && Tg > 0, "shape");
+  IDX_CHECK(ws && ws_bytes >= cond_workspace_bytes(B, M, Tg), "workspace too small");
+  const int Hc = cfg.codec_hidden, LC = cfg.lr_channels;
+  CondBuffers w = carve_cond(*this, ws, B, M, Tg);
+  // host-side index tables: code ids, and torch's 'nearest' source row for every target frame
+  std::vector<long long> hc((size_t)B * M);
+  IDX_HIP(hipMemcpyAsync(hc.data(), codes, hc.size() * sizeof(long long), hipMemcpyDeviceToHost, st));
+  IDX_HIP(hipStreamSynchronize(st));
+  std::vector<int> ic((size_t)B * M), ir((size_t)B * M), ii((size_t)B * Tg, -1), tl(B);
+  for (int b = 0; b < B; ++b) {
+    const int mb = code_lens_host[b], tb = target_lens_host[b];
+    IDX_CHECK(mb > 0 && mb <= M && tb > 0 && tb <= Tg, "code_lens / target_lens out of range");
+    tl[b] = tb;
+    for (int i = 0; i < M; ++i) {
+      const long long cde = hc[(size_t)b * M + i];
+      IDX_CHECK(i >= mb || (cde >= 0 && cde < cfg.codebook_size), "semantic code out of the codebook");
+      ic[(size_t)b * M + i] = i < mb ? (int)cde : -1;
+      ir[(size_t)b * M + i] = i < mb ? b * M + i : -1;
+    }
+    // F.interpolate(mode='nearest'): src = min(floor(dst * (float)in / out), in - 1), float32 arithmetic
+    const float scale = (float)mb / (float)tb;
+    for (int j = 0; j < tb; ++j) ii[(size_t)b * Tg + j] = b * M + std::min((int)std::floor((float)j * scale), mb - 1);
+  }
+  IDX_HIP(hipMemcpyAsync(w.idx_code, ic.data(), ic.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  IDX_HIP(hipMemcpyAsync(w.idx_row, ir.data(), ir.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  IDX_HIP(hipMemcpyAsync(w.idx_interp, ii.data(), ii.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  IDX_HIP(hipMemcpyAsync(w.tlen, tl.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
+  IDX_HIP(hipStreamSynchronize(st));
+  const int rowsM = B * M, rowsT = B * Tg;
+  // gpt_layer: 1280 -> 256 -> 128 -> 1024 (commons.py:413)
+  if (gemm(gl[0], latent, cfg.gpt_dim, w.a, gl[0].N, rowsM, st) || gemm(gl[1], w.a, gl[0].N, w.b, gl[1].N, rowsM, st) ||
+      gemm(gl[2], w.b, gl[1].N, w.a, Hc, rowsM, st)) return 1;
+  // S_infer = vq2emb(codes) + latent (infer_v2.py:841-843)
+  GatherArgs ga;
+  ga.out = w.s; ga.ld_out = Hc; ga.d = Hc;
+  ga.table[0] = vq_table; ga.idx[0] = w.idx_code;
+  ga.table[1] = w.a; ga.idx[1] = w.idx_row;
+  if (gather_sum_rows(ga, rowsM, st)) return 1;
+  // content_in_proj, nearest interpolation M_b -> Tg_b (rows beyond Tg_b are zero)
+  if (gemm(lr_in, w.s, Hc, w.a, LC, rowsM, st)) return 1;
+  GatherArgs gi;
+  gi.out = w.b; gi.ld_out = LC; gi.d = LC; gi.table[0] = w.a; gi.idx[0] = w.idx_interp;
+  if (gather_sum_rows(gi, rowsT, st)) return 1;
+  float* cur = w.b;
+  float* other = w.a;
+  for (int n = 0; n < cfg.lr_num_convs; ++n) {
+    GemmArgs g;
+    g.x = cur; g.ldx = LC; g.y = other; g.ldy = LC; g.M = rowsT; g.taps = 3; g.seq_len = Tg; g.dil = 1; g.pad_left = 1; g.pad_mode = 0;
+    if (gemm_tn_forward(lr_conv[n], g, st)) return 1;
+    if (groupnorm1_mish(cur, other, lr_gn_g[n], lr_gn_b[n], w.tlen, B, Tg, LC, 1e-5f, w.stats, st)) return 1;
+  }
+  GemmArgs o;
+  o.x = cur; o.ldx = LC; o.y = cond_out; o.ldy = LC; o.M = rowsT; o.seq_len = Tg; o.row_len = w.tlen;    // * mask
+  return gemm_tn_forward(lr_out, o, st);
+}
+
+}  // namespace idxtts

@@ -21,6 +21,8 @@ SYMBOLS = [
     "idxtts_profile_enable", "idxtts_profile_num_kernels", "idxtts_profile_kernel_name", "idxtts_profile_read",
     "idxtts_linear_create", "idxtts_linear_fwd", "idxtts_linear_destroy", "idxtts_attention_fwd", "idxtts_layernorm_fwd",
     "idxtts_gpt_create", "idxtts_gpt_workspace_bytes", "idxtts_gpt_embed", "idxtts_gpt_generate", "idxtts_gpt_latent",
+    "idxtts_s2mel_create", "idxtts_s2mel_cond_workspace_bytes", "idxtts_s2mel_prepare_cond",
+    "idxtts_s2mel_cfm_workspace_bytes", "idxtts_s2mel_cfm",
 ]
 
 
@@ -36,6 +38,14 @@ class BigVGANConfigC(ctypes.Structure):
 class GPTConfigC(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("model_dim", "heads", "layers", "number_mel_codes", "number_text_tokens",
                                      "start_mel_token", "stop_mel_token", "mel_pos_len", "text_pos_len")]
+
+
+class S2MelConfigC(ctypes.Structure):
+    _fields_ = ([(n, c_int) for n in ("hidden_dim", "num_heads", "depth", "in_channels", "content_dim", "style_dim", "wn_hidden",
+                                      "wn_layers", "wn_kernel", "wn_dilation_rate", "lr_channels", "lr_in_channels",
+                                      "lr_num_convs", "gpt_dim")]
+                + [("gpt_layer_dims", c_int * 3)]
+                + [(n, c_int) for n in ("codebook_size", "codebook_dim", "codec_hidden")] + [("norm_eps", c_float)])
 
 
 _lib = None
@@ -81,6 +91,15 @@ def load() -> ctypes.CDLL:
     lib.idxtts_gpt_generate.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, POINTER(c_int),
                                         c_void_p, c_void_p, c_size_t, c_int, c_void_p]
     lib.idxtts_gpt_latent.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.idxtts_s2mel_create.argtypes = [POINTER(S2MelConfigC), POINTER(c_void_p)]
+    lib.idxtts_s2mel_cond_workspace_bytes.argtypes = [c_void_p, c_int, c_int, c_int]
+    lib.idxtts_s2mel_cond_workspace_bytes.restype = c_size_t
+    lib.idxtts_s2mel_prepare_cond.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                              c_void_p, c_size_t, c_void_p]
+    lib.idxtts_s2mel_cfm_workspace_bytes.argtypes = [c_void_p, c_int, c_int, c_int]
+    lib.idxtts_s2mel_cfm_workspace_bytes.restype = c_size_t
+    lib.idxtts_s2mel_cfm.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]
     lib.idxtts_profile_enable.argtypes = [c_int]
     lib.idxtts_profile_kernel_name.argtypes = [c_int]
     lib.idxtts_profile_kernel_name.restype = c_char_p
