@@ -137,9 +137,11 @@ int idxtts_gpt_embed(idxtts_ctx* ctx, float* out, int rows, const int* text_ids,
 int idxtts_gpt_generate(idxtts_ctx* ctx, const float* inputs_embeds, const int* pad_left, int B, int P, int max_new_tokens,
                         float repetition_penalty, long long* codes, int* n_steps, float* logits_out, void* workspace,
                         size_t workspace_bytes, int use_graph, void* stream);
-/* Latent pass: full causal forward over emb [B][S][d]; latent[b][i] = final_norm(ln_f(h[b][mel_start + i])), i < M. */
-int idxtts_gpt_latent(idxtts_ctx* ctx, const float* emb, int B, int S, int mel_start, int M, float* latent, void* workspace,
-                      size_t workspace_bytes, void* stream);
+/* Latent pass: full causal forward over emb [B][S][d]; latent[b][i] = final_norm(ln_f(h[b][mel_start + i])), i < M.
+ * pad_left: optional HOST int32 [B], leading rows of each sequence that are padding (masked as keys), so rows with
+ * shorter texts can share a batch and still reproduce the reference's per-utterance (B=1) result. */
+int idxtts_gpt_latent(idxtts_ctx* ctx, const float* emb, const int* pad_left, int B, int S, int mel_start, int M, float* latent,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- s2mel stage (reference: infer_v2.py:835-856; MyModel commons.py:390-420) -------------------------
  * State-dict keys: "cfm.estimator.*", "length_regulator.*", "gpt_layer.{0,1,2}.*" (s2mel.pth['net'][...], weight-norm

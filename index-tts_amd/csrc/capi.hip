@@ -280,11 +280,11 @@ int idxtts_gpt_generate(idxtts_ctx* ctx, const float* inputs_embeds, const int* 
   API_END
 }
 
-int idxtts_gpt_latent(idxtts_ctx* ctx, const float* emb, int B, int S, int mel_start, int M, float* latent, void* workspace,
-                      size_t workspace_bytes, void* stream) {
+int idxtts_gpt_latent(idxtts_ctx* ctx, const float* emb, const int* pad_left, int B, int S, int mel_start, int M, float* latent,
+                      void* workspace, size_t workspace_bytes, void* stream) {
   API_BEGIN
   GPT_MODEL(ctx);
-  return m->latent(emb, B, S, mel_start, M, latent, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+  return m->latent(emb, pad_left, B, S, mel_start, M, latent, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
   API_END
 }
 

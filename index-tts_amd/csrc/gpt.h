@@ -48,7 +48,8 @@ struct GPTModel : ModelBase {
   int decode_step(const Buffers& w, int B, float penalty, long long* codes, int codes_ld, float* logits_base, hipStream_t st);
   int generate(const float* inputs_embeds, const int* pad_left_host, int B, int P, int max_new, float penalty, long long* codes,
                int* n_steps_out, float* logits_out, void* ws, size_t ws_bytes, int use_graph, hipStream_t st);
-  int latent(const float* emb, int B, int S, int mel_start, int M, float* latent_out, void* ws, size_t ws_bytes, hipStream_t st);
+  int latent(const float* emb, const int* pad_left_host, int B, int S, int mel_start, int M, float* latent_out, void* ws, size_t ws_bytes,
+             hipStream_t st);
   int embed(float* out, int rows, const int* text_ids, const int* text_pos_idx, const int* mel_ids, const int* mel_pos_idx,
             const float* extra, const int* extra_idx, hipStream_t st);
 };

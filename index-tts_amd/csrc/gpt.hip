@@ -362,16 +362,23 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
   return 0;
 }
 
-int GPTModel::latent(const float* emb, int B, int S, int mel_start, int M, float* latent_out, void* ws, size_t ws_bytes,
-                     hipStream_t st) {
+int GPTModel::latent(const float* emb, const int* pad_left_host, int B, int S, int mel_start, int M, float* latent_out, void* ws,
+                     size_t ws_bytes, hipStream_t st) {
   IDX_CHECK(emb && latent_out, "null pointer");
   IDX_CHECK(B > 0 && S > 0 && M > 0 && mel_start >= 0 && mel_start + M <= S, "shape");
   IDX_CHECK(ws && ws_bytes >= workspace_bytes(B, S, 0), "workspace too small");
   const int d = cfg.model_dim;
   Buffers w = carve(ws, B, S, 0);
+  const int* kstart = nullptr;
+  if (pad_left_host) {      // rows with shorter texts are left-padded; padded keys are masked exactly like the decode prompt
+    for (int b = 0; b < B; ++b) IDX_CHECK(pad_left_host[b] >= 0 && pad_left_host[b] < mel_start, "pad_left out of range");
+    IDX_HIP(hipMemcpyAsync(w.kstart, pad_left_host, B * sizeof(int), hipMemcpyHostToDevice, st));
+    IDX_HIP(hipStreamSynchronize(st));
+    kstart = w.kstart;
+  }
   IDX_HIP(hipMemcpyAsync(w.x, emb, (size_t)B * S * d * sizeof(float), hipMemcpyDeviceToDevice, st));
   for (int li = 0; li < cfg.layers; ++li)
-    if (layer_full(li, w, B, S, nullptr, false, st)) return 1;
+    if (layer_full(li, w, B, S, kstart, false, st)) return 1;
   RowsNormArgs n;     // final_norm(ln_f(h)) on the mel rows only (model_v2.py:611, 723)
   n.x_in = w.x + (size_t)mel_start * d; n.ld_in = d; n.in_rows_per_batch = M; n.in_batch_stride = (long)S * d;
   n.y = latent_out; n.ld_y = d; n.M = B * M; n.d = d; n.mode = NORM_LN_LN;

@@ -90,7 +90,7 @@ def load() -> ctypes.CDLL:
     lib.idxtts_gpt_embed.argtypes = [c_void_p, c_void_p, c_int] + [c_void_p] * 7
     lib.idxtts_gpt_generate.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, POINTER(c_int),
                                         c_void_p, c_void_p, c_size_t, c_int, c_void_p]
-    lib.idxtts_gpt_latent.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.idxtts_gpt_latent.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.idxtts_s2mel_create.argtypes = [POINTER(S2MelConfigC), POINTER(c_void_p)]
     lib.idxtts_s2mel_cond_workspace_bytes.argtypes = [c_void_p, c_int, c_int, c_int]
     lib.idxtts_s2mel_cond_workspace_bytes.restype = c_size_t

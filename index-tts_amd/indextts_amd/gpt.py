@@ -181,10 +181,10 @@ class UnifiedVoice:
         M = codes.shape[1]
         tl = np.asarray(text_lengths.detach().cpu() if isinstance(text_lengths, torch.Tensor) else text_lengths).reshape(-1)
         ml = np.asarray(mel_codes_lengths.detach().cpu() if isinstance(mel_codes_lengths, torch.Tensor) else mel_codes_lengths).reshape(-1)
-        for b in range(B):      # set_text_padding / set_mel_padding (model_v2.py:569-595)
-            text[b, int(tl[min(b, len(tl) - 1)]):] = cfg.stop_text_token
-            codes[b, int(ml[min(b, len(ml) - 1)]):] = cfg.stop_mel_token
-        tin = np.concatenate([np.full((B, 1), cfg.start_text_token), text, np.full((B, 1), cfg.stop_text_token)], 1)
+        tlv = [int(tl[min(b, len(tl) - 1)]) for b in range(B)]
+        mlv = [int(ml[min(b, len(ml) - 1)]) for b in range(B)]
+        for b in range(B):      # set_mel_padding (model_v2.py:569-581)
+            codes[b, mlv[b]:] = cfg.stop_mel_token
         min_ = np.concatenate([np.full((B, 1), cfg.start_mel_token), codes, np.full((B, 1), cfg.stop_mel_token)], 1)
         conds = self.conds_latent(speech_conditioning_latent, emo_vec)
         nc = conds.shape[1]
@@ -192,15 +192,24 @@ class UnifiedVoice:
         tid = -np.ones((B, S), np.int32); tpos = -np.ones((B, S), np.int32)
         mid = -np.ones((B, S), np.int32); mpos = -np.ones((B, S), np.int32)
         eidx = -np.ones((B, S), np.int32)
+        pad_left = np.zeros(B, np.int32)
         for b in range(B):
-            eidx[b, :nc] = np.arange(nc) + b * nc
-            tid[b, nc:nc + L + 2] = tin[b]; tpos[b, nc:nc + L + 2] = np.arange(L + 2)
-            mid[b, nc + L + 2:] = min_[b]; mpos[b, nc + L + 2:] = np.arange(M + 2)
+            # row layout [pad][conds][start, text_b, stop][start, codes, stop, stop]; a row whose text is shorter than L is
+            # LEFT-padded (and the pad masked), which reproduces the reference's unpadded B=1 call for that row
+            pad = L - tlv[b]
+            pad_left[b] = pad
+            trow = np.concatenate([[cfg.start_text_token], text[b, :tlv[b]], [cfg.stop_text_token]])
+            eidx[b, pad:pad + nc] = np.arange(nc) + b * nc
+            tid[b, pad + nc:nc + L + 2] = trow
+            tpos[b, pad + nc:nc + L + 2] = np.arange(tlv[b] + 2)
+            mid[b, nc + L + 2:] = min_[b]
+            mpos[b, nc + L + 2:] = np.arange(M + 2)
         emb = self._embed(B * S, tid.reshape(-1), tpos.reshape(-1), mid.reshape(-1), mpos.reshape(-1),
                           conds.reshape(-1, cfg.model_dim), eidx.reshape(-1))
         latent = torch.empty(B, M, cfg.model_dim, device=self.device, dtype=torch.float32)
         ws = self._workspace(B, S, 0)
-        _lib.check(_lib.load().idxtts_gpt_latent(self._h, _lib.ptr(emb), B, S, nc + L + 2, M, _lib.ptr(latent), _lib.ptr(ws),
+        pl = pad_left.ctypes.data_as(c_void_p) if pad_left.any() else c_void_p(0)
+        _lib.check(_lib.load().idxtts_gpt_latent(self._h, _lib.ptr(emb), pl, B, S, nc + L + 2, M, _lib.ptr(latent), _lib.ptr(ws),
                                                  ws.numel(), _lib.current_stream()))
         return latent
 

@@ -1,0 +1,253 @@
+"""Host-side mirror of `indextts.infer_v2.IndexTTS2` for the hot path (reference infer_v2.py:69-937).
+
+Scope: the three hot stages -- GPT decode + latent pass, s2mel, BigVGAN -- and the segment loop
+that sequences them (infer_v2.py:732-881), with the reference's return contract (905-937).  The prompt-side
+encoders (w2v-bert, RepCodec, CAMPPlus, conformer/perceiver; infer_v2.py:618-696, model_v2.py:627-671) and the
+text front-end are "next" rows (§8f): their OUTPUTS enter here as a `PromptConditioning` bundle and token ids.
+"""
+from __future__ import annotations
+
+import os
+import time
+import warnings
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import synth
+from .config import PipelineConfig
+from .gpt import UnifiedVoice
+from .s2mel import S2Mel
+from .vocoder import BigVGAN
+
+
+@dataclass
+class InferenceResult:                       # infer_v2.py:58-66
+    sampling_rate: int
+    audio: object
+    duration_sec: float
+    saved_path: Optional[str]
+    rtf: Optional[float]
+
+
+@dataclass
+class PromptConditioning:
+    """What the reference caches per prompt (infer_v2.py:654-658, 693-694) after its encoders have run."""
+    spk_cond_latent: torch.Tensor     # [1, 32, d]   get_conditioning(spk_cond_emb)           model_v2.py:819
+    emo_vec: torch.Tensor             # [1, d]       merge_emovec(...)                        model_v2.py:904-910
+    style: torch.Tensor               # [1, 192]     CAMPPlus                                 infer_v2.py:647
+    prompt_condition: torch.Tensor    # [1, Tp, 512] length_regulator(S_ref)                  infer_v2.py:649
+    ref_mel: torch.Tensor             # [1, 80, Tp]  mel_fn(prompt audio)                     infer_v2.py:640
+
+    FIELDS = ("spk_cond_latent", "emo_vec", "style", "prompt_condition", "ref_mel")
+
+    @staticmethod
+    def synthetic(cfg: PipelineConfig, prompt_frames: int = 689, tag: str = "prompt") -> "PromptConditioning":
+        """Seeded stand-in for an 8 s prompt (Tp = 689)."""
+        d = cfg.gpt.model_dim
+        t = lambda n, shape, s, o=0.0: torch.from_numpy(synth.uniform(f"{tag}/{n}", shape, s, o))
+        return PromptConditioning(
+            t("latent", (1, cfg.gpt.cond_latents, d), 0.5), t("emo", (1, d), 0.3), t("style", (1, cfg.s2mel.style_dim), 1.0),
+            t("prompt_condition", (1, prompt_frames, cfg.s2mel.content_dim), 1.0),
+            t("ref_mel", (1, cfg.s2mel.in_channels, prompt_frames), 2.6, -4.0))
+
+    def to(self, device) -> "PromptConditioning":
+        return PromptConditioning(*[getattr(self, f).to(device, torch.float32).contiguous() for f in self.FIELDS])
+
+    # one flat buffer for the RCCL broadcast ("one packed buffer")
+    def pack(self) -> torch.Tensor:
+        return torch.cat([getattr(self, f).reshape(-1) for f in self.FIELDS])
+
+    def shapes(self):
+        return [tuple(getattr(self, f).shape) for f in self.FIELDS]
+
+    @staticmethod
+    def unpack(flat: torch.Tensor, shapes) -> "PromptConditioning":
+        out, off = [], 0
+        for shp in shapes:
+            n = int(np.prod(shp))
+            out.append(flat[off:off + n].reshape(shp))
+            off += n
+        return PromptConditioning(*out)
+
+
+class IndexTTS2:
+    """Drop-in for the hot path of `indextts.infer_v2.IndexTTS2`.
+
+    Construct from state dicts (reference key layout) with `from_state_dicts`, or from a checkpoint directory
+    with the reference's constructor signature (infer_v2.py:69-72) when `gpt.pth`, `s2mel.pth` and the BigVGAN
+    generator are present there (they are not shipped offline).
+    """
+
+    def __init__(self, cfg_path="checkpoints/config.yaml", model_dir="checkpoints", use_fp16=False, device=None,
+                 use_cuda_kernel=None, use_deepspeed=False, use_accel=False, use_torch_compile=False):
+        if use_fp16:
+            warnings.warn("use_fp16 is ignored: the HIP path computes in float32 (parity with the CPU reference)")
+        need = [os.path.join(model_dir, f) for f in ("gpt.pth", "s2mel.pth")]
+        missing = [p for p in need if not os.path.exists(p)]
+        if missing:
+            raise FileNotFoundError(f"IndexTTS-2 checkpoints not found ({missing}); use IndexTTS2.from_state_dicts(...)")
+        from .checkpoint import load_reference_checkpoints
+        gpt_sd, s2mel_sd, voc_sd = load_reference_checkpoints(model_dir)
+        self._init(PipelineConfig(), gpt_sd, s2mel_sd, voc_sd, device)
+
+    @classmethod
+    def from_state_dicts(cls, cfg: PipelineConfig, gpt_sd, s2mel_sd, bigvgan_sd, device=None) -> "IndexTTS2":
+        self = cls.__new__(cls)
+        self._init(cfg, gpt_sd, s2mel_sd, bigvgan_sd, device)
+        return self
+
+    def _init(self, cfg, gpt_sd, s2mel_sd, bigvgan_sd, device):
+        if device is None:
+            device = f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cpu"
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("IndexTTS2 (HIP path) needs an MI355X device; there is no CPU fallback")
+        self.cfg = cfg
+        self.gpt = UnifiedVoice(gpt_sd, cfg.gpt, device=self.device)
+        self.s2mel = S2Mel(s2mel_sd, cfg.s2mel, device=self.device)
+        self.bigvgan = BigVGAN(bigvgan_sd, cfg.bigvgan)
+        self.stop_mel_token = cfg.gpt.stop_mel_token
+        self.model_version = 2.0
+        self.gr_progress = None
+        self._diffusion_steps = int(os.environ.get("TARS_DIFFUSION_STEPS", cfg.diffusion_steps))   # infer_v2.py:125
+        self._cfg_rate = float(os.environ.get("TARS_CFG_RATE", cfg.cfg_rate))                      # infer_v2.py:126
+        self.last_stage_times = {}
+
+    # ------------------------------------------------------------------------------------------
+    def synthesize_batch(self, text_tokens: torch.Tensor, cond: PromptConditioning, max_mel_tokens: int = 1500,
+                         repetition_penalty: float = 10.0, noise: Optional[torch.Tensor] = None, sync_timers: bool = False,
+                         return_intermediates: bool = False):
+        """One batch of single-segment utterances sharing a prompt: the body of the reference's segment loop
+        (infer_v2.py:732-881) for B rows at once.  text_tokens [B, L] (right-padded with stop_text_token).
+        Returns a list of B waveforms, float32 [1, n_b] in int16 range (infer_v2.py:866)."""
+        dev = self.device
+        c = cond.to(dev)
+        B = text_tokens.shape[0]
+        times = {}
+
+        def tick():
+            if sync_timers:
+                torch.cuda.synchronize(dev)
+            return time.perf_counter()
+
+        t0 = tick()
+        lat = c.spk_cond_latent.expand(B, -1, -1) if c.spk_cond_latent.shape[0] == 1 else c.spk_cond_latent
+        emo = c.emo_vec.expand(B, -1) if c.emo_vec.shape[0] == 1 else c.emo_vec
+        codes, _ = self.gpt.inference_speech(lat, text_tokens, emo_vec=emo, max_generate_length=max_mel_tokens,
+                                             repetition_penalty=repetition_penalty, do_sample=False, num_beams=1)
+        t1 = tick()
+        times["gpt_gen_time"] = t1 - t0
+        # trim at the first stop token (infer_v2.py:795-807)
+        hc = codes.cpu().numpy()
+        code_lens = []
+        for row in hc:
+            hits = np.nonzero(row == self.stop_mel_token)[0]
+            code_lens.append(int(hits[0]) if len(hits) else len(row))
+        if not all(cl > 0 for cl in code_lens):
+            raise RuntimeError("a row produced the stop token first: nothing to synthesise")
+        if any(cl == len(row) for cl, row in zip(code_lens, hc)) and hc.shape[1] >= max_mel_tokens:
+            warnings.warn(f"WARN: generation stopped due to exceeding `max_mel_tokens` ({max_mel_tokens}).", RuntimeWarning)
+        max_len = max(code_lens)
+        codes = codes[:, :max_len].contiguous()
+        code_lens_t = torch.tensor(code_lens, dtype=torch.long)
+        # per-row text length (rows are right-padded with stop_text_token); the latent pass left-pads + masks shorter rows
+        tt = torch.as_tensor(text_tokens).cpu()
+        text_lens = ((tt != self.cfg.gpt.stop_text_token) & (tt != self.cfg.gpt.start_text_token)).sum(1)
+        latent = self.gpt.forward(lat, text_tokens, text_lens, codes, code_lens_t, emo_vec=emo)
+        t2 = tick()
+        times["gpt_forward_time"] = t2 - t1
+        condv, target_lens = self.s2mel.prepare_condition(latent, codes, code_lens_t)
+        Tp = c.prompt_condition.shape[1]
+        Tg = condv.shape[1]
+        cat_condition = torch.cat([c.prompt_condition.expand(B, -1, -1), condv], dim=1)     # infer_v2.py:850
+        x_lens = target_lens.cpu() + Tp
+        if noise is None:
+            noise = torch.randn([B, self.cfg.s2mel.in_channels, Tp + Tg], device=dev)
+        mel = self.s2mel.cfm_inference(cat_condition, x_lens, c.ref_mel.expand(B, -1, -1), c.style.expand(B, -1), None,
+                                       self._diffusion_steps, inference_cfg_rate=self._cfg_rate, z=noise)
+        vc_target = mel[:, :, Tp:]                                                          # infer_v2.py:856
+        t3 = tick()
+        times["s2mel_time"] = t3 - t2
+        # vocoder: utterances of equal length go through together; others one by one, so that every conv sees the
+        # zero padding of its OWN sequence end exactly as the reference's B=1 call does (infer_v2.py:860)
+        wavs: List[Optional[torch.Tensor]] = [None] * B
+        tl = target_lens.cpu().tolist()
+        for length in sorted(set(tl)):
+            rows = [b for b in range(B) if tl[b] == length]
+            m = vc_target[rows, :, :length].contiguous()
+            w = self.bigvgan(m.float())
+            w = torch.clamp(32767 * w, -32767.0, 32767.0)                                   # infer_v2.py:866
+            for i, b in enumerate(rows):
+                wavs[b] = w[i]
+        t4 = tick()
+        times["bigvgan_time"] = t4 - t3
+        self.last_stage_times = times
+        if return_intermediates:
+            return wavs, {"codes": codes, "code_lens": code_lens, "latent": latent, "cond": condv, "mel": vc_target,
+                          "target_lens": tl}
+        return wavs
+
+    # ------------------------------------------------------------------------------------------
+    def interval_silence(self, sampling_rate=22050, interval_silence=200):                 # infer_v2.py:484-497
+        n = int(sampling_rate * interval_silence / 1000.0)
+        return torch.zeros(1, n, device=self.device)
+
+    def infer(self, spk_audio_prompt, text, output_path, emo_audio_prompt=None, emo_alpha=1.0, emo_vector=None,
+              use_emo_text=False, emo_text=None, use_random=False, interval_silence=200, verbose=False,
+              max_text_tokens_per_segment=120, stream_return=False, more_segment_before=0, return_audio=False,
+              return_numpy=False, **generation_kwargs):
+        """Reference signature (infer_v2.py:541-546).  On this path `spk_audio_prompt` must be a PromptConditioning and
+        `text` a list of token-id segments (List[List[int]]) or one segment (List[int] / 1-D tensor)."""
+        if stream_return and return_audio:
+            raise ValueError("stream_return and return_audio are mutually exclusive")                # infer_v2.py:575-576
+        if not isinstance(spk_audio_prompt, PromptConditioning):
+            raise NotImplementedError("prompt encoders (w2v-bert / RepCodec / CAMPPlus / conformer-perceiver) are outside this "
+                                      "hot path (SURVEY.md §8f rank 1): pass a PromptConditioning")
+        if isinstance(text, str):
+            raise NotImplementedError("the text front-end (tokenizer/segmenter) is outside this hot path (SURVEY.md §8f rank 3): "
+                                      "pass token ids")
+        if emo_audio_prompt is not None or emo_vector is not None or use_emo_text:
+            raise NotImplementedError("emotion routing happens upstream: fold it into PromptConditioning.emo_vec")
+        segs = text if (len(text) and isinstance(text[0], (list, tuple, np.ndarray, torch.Tensor))) else [text]
+        segs = [torch.as_tensor(s, dtype=torch.long).reshape(1, -1) for s in segs]
+        if not segs or any(s.numel() == 0 for s in segs):
+            return None                                                                              # infer_v2.py:566-567
+        do_sample = generation_kwargs.pop("do_sample", False)
+        num_beams = generation_kwargs.pop("num_beams", 1)
+        if do_sample or num_beams != 1:
+            raise NotImplementedError("only greedy decoding is implemented on the HIP path (SURVEY.md §8f rank 2)")
+        repetition_penalty = generation_kwargs.pop("repetition_penalty", 10.0)
+        max_mel_tokens = generation_kwargs.pop("max_mel_tokens", 1500)
+        for k in ("top_p", "top_k", "temperature", "length_penalty"):
+            generation_kwargs.pop(k, None)
+        start = time.perf_counter()
+        wavs = []
+        for s in segs:                                                                               # segment loop, infer_v2.py:732
+            w = self.synthesize_batch(s, spk_audio_prompt, max_mel_tokens=max_mel_tokens, repetition_penalty=repetition_penalty)[0]
+            wavs.append(w)
+        out = []
+        sil = self.interval_silence(interval_silence=interval_silence)
+        for i, w in enumerate(wavs):                                                                 # insert_interval_silence 499-522
+            out.append(w)
+            if i + 1 < len(wavs):
+                out.append(sil)
+        wav = torch.cat(out, dim=1).cpu()
+        total = time.perf_counter() - start
+        mono = wav.squeeze(0).contiguous()
+        sr = 22050
+        wav_length = mono.shape[-1] / sr
+        rtf = (total / wav_length) if wav_length else None
+        saved = None
+        if output_path and not return_audio:
+            from .wavio import write_wav_int16
+            if os.path.dirname(output_path):
+                os.makedirs(os.path.dirname(output_path), exist_ok=True)
+            write_wav_int16(output_path, mono.to(torch.int16).numpy(), sr)
+            return output_path                                                                       # infer_v2.py:917
+        if return_audio:
+            audio = mono.clone()
+            return InferenceResult(sr, audio.numpy().copy() if return_numpy else audio, float(wav_length), saved, rtf)
+        return (sr, mono.unsqueeze(0).to(torch.int16).numpy().T)                                     # infer_v2.py:935-937

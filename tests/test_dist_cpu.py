@@ -1,0 +1,76 @@
+"""CPU, world_size 2, gloo: the data-parallel exchange steps (conditioning broadcast, waveform gather) and sharding."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from indextts_amd.config import PipelineConfig
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from indextts_amd.dist import broadcast_conditioning, gather_waveforms, shard_bounds
+    from indextts_amd.infer_v2 import PromptConditioning
+    cfg = PipelineConfig.tiny()
+    ref = PromptConditioning.synthetic(cfg, prompt_frames=13, tag="dist/prompt")
+    shapes = ref.shapes()
+    got = broadcast_conditioning(ref if rank == 0 else None, shapes, torch.device("cpu"))
+    ok = all(torch.equal(getattr(got, f), getattr(ref, f)) for f in PromptConditioning.FIELDS)
+    lo, hi = shard_bounds(5, world, rank)
+    wavs = [torch.full((1, 10 + 3 * i + rank), float(100 * rank + i)) for i in range(3)]
+    res = gather_waveforms(wavs, dst=0)
+    if rank == 0:
+        for r in range(world):
+            for i in range(3):
+                w = res[r][i]
+                ok = ok and w.shape == (1, 10 + 3 * i + r) and bool((w == 100 * r + i).all())
+    else:
+        ok = ok and res is None
+    q.put((rank, ok, (lo, hi)))
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_gather_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in results] == [True, True]
+    assert [r[2] for r in results] == [(0, 3), (3, 5)]
+
+
+def test_shard_bounds_cover_everything():
+    from indextts_amd.dist import shard_bounds, sort_by_length
+    for n in (0, 1, 7, 256):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+    assert sort_by_length([5, 2, 9, 2]) == [1, 3, 0, 2]
+
+
+def test_conditioning_pack_roundtrip():
+    from indextts_amd.infer_v2 import PromptConditioning
+    c = PromptConditioning.synthetic(PipelineConfig.tiny(), prompt_frames=9)
+    r = PromptConditioning.unpack(c.pack(), c.shapes())
+    assert all(torch.equal(getattr(c, f), getattr(r, f)) for f in PromptConditioning.FIELDS)

@@ -1,0 +1,76 @@
+"""GPU parity of the whole hot path: IndexTTS2.synthesize_batch (GPT decode -> latent pass -> s2mel -> BigVGAN, one ragged
+batch) against the per-utterance CPU oracle that follows infer_v2.py:732-881, at reduced width."""
+import numpy as np
+import pytest
+import torch
+
+from indextts_amd import synth, weights
+from indextts_amd.config import PipelineConfig
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(device, eos_bias):
+    from indextts_amd.infer_v2 import IndexTTS2, PromptConditioning
+    cfg = PipelineConfig.tiny()
+    wg = weights.synth_gpt_weights(cfg.gpt, tag="t/pipe/gpt")
+    wg["mel_head.bias"] = wg["mel_head.bias"].copy()
+    wg["mel_head.bias"][cfg.gpt.stop_mel_token] = eos_bias
+    ws = weights.synth_s2mel_weights(cfg.s2mel, tag="t/pipe/s2mel")
+    wv = weights.synth_bigvgan_weights(cfg.bigvgan, tag="t/pipe/voc")
+    tts = IndexTTS2.from_state_dicts(cfg, wg, ws, wv, device=device)
+    cond = PromptConditioning.synthetic(cfg, prompt_frames=11, tag="t/pipe/prompt")
+    return cfg, wg, ws, wv, tts, cond
+
+
+def test_batch_equals_per_utterance_reference_flow(device):
+    from oracle import pipeline as op
+    cfg, wg, ws, wv, tts, cond = _build(device, eos_bias=2.2)
+    B, L, MAXM = 4, 10, 24
+    text = torch.from_numpy(synth.integers("t/pipe/text", (B, L), 2, cfg.gpt.number_text_tokens))
+    lens = [10, 7, 10, 4]
+    for b, n in enumerate(lens):
+        text[b, n:] = cfg.gpt.stop_text_token
+    Tp = cond.ref_mel.shape[-1]
+    noise = torch.from_numpy(synth.uniform("t/pipe/noise", (B, cfg.s2mel.in_channels, Tp + int(MAXM * 1.72) + 2), 1.7))
+    # the batch: noise is sliced to the batch's longest sequence exactly as each oracle call slices its own row
+    twg = {k: torch.from_numpy(v) for k, v in wg.items()}
+    tws = {k: torch.from_numpy(v) for k, v in ws.items()}
+    refs = [op.synthesize_one(twg, tws, wv, cfg, text[b:b + 1, :lens[b]], cond, noise[b:b + 1], MAXM) for b in range(B)]
+    Tg_max = max(int(r["mel"].shape[-1]) for r in refs)
+    wavs, mid = tts.synthesize_batch(text, cond, max_mel_tokens=MAXM, noise=noise[:, :, :Tp + Tg_max].to(device),
+                                     return_intermediates=True)
+    code_lens = [r["code_len"] for r in refs]
+    assert len(set(code_lens)) > 1, "fixture should be ragged"
+    for b in range(B):
+        r = refs[b]
+        n = r["code_len"]
+        assert mid["code_lens"][b] == n
+        assert np.array_equal(mid["codes"][b, :n].cpu().numpy(), r["codes"][0].numpy())          # greedy tokens: bit-exact
+        assert (mid["latent"][b, :n].cpu() - r["latent"][0]).abs().max().item() <= 1e-4
+        Tg = r["mel"].shape[-1]
+        mel_err = (mid["mel"][b, :, :Tg].cpu() - r["mel"][0]).abs()
+        assert mel_err.mean().item() <= 1e-4 and mel_err.max().item() <= 2e-3                     # mel L1 (target 1e-3)
+        w = wavs[b].cpu()
+        assert w.shape == r["wav"].shape
+        assert (w - r["wav"]).abs().max().item() <= 32767 * 2e-4                                  # waveform, int16 units
+
+
+def test_infer_return_contract(device, tmp_path):
+    from indextts_amd.infer_v2 import InferenceResult
+    cfg, wg, ws, wv, tts, cond = _build(device, eos_bias=2.2)
+    seg = synth.integers("t/pipe/seg", (2, 6), 2, cfg.gpt.number_text_tokens).tolist()
+    sr, wav = tts.infer(cond, seg, None, max_mel_tokens=16)
+    assert sr == 22050 and wav.dtype == np.int16 and wav.ndim == 2 and wav.shape[1] == 1
+    res = tts.infer(cond, seg[0], None, return_audio=True, return_numpy=True, max_mel_tokens=16)
+    assert isinstance(res, InferenceResult) and res.sampling_rate == 22050 and res.duration_sec > 0 and res.rtf > 0
+    path = tts.infer(cond, seg[0], str(tmp_path / "o.wav"), max_mel_tokens=16)
+    assert path.endswith("o.wav")
+    import wave
+    with wave.open(path) as f:
+        assert f.getframerate() == 22050 and f.getnframes() == int(round(res.duration_sec * 22050))
+    assert tts.infer(cond, [], None) is None
+    with pytest.raises(ValueError):
+        tts.infer(cond, seg[0], None, stream_return=True, return_audio=True)
+    with pytest.raises(NotImplementedError):
+        tts.infer("examples/voice_01.wav", seg[0], None)
