@@ -7,11 +7,15 @@
 Metric (BASELINE.json): synthesised audio seconds per wall-second (whole job, all GPUs) and RTF.
 A "step" = one pass of the hot path over one batch of synthetic inputs already resident in HBM.
 Workloads (BASELINE.json `configs`):
+  pipeline  configs[2] (default): IndexTTS-2 full pipeline GPT decode -> latent pass -> s2mel (CFM 20 steps, cfg 0.7) ->
+            BigVGAN, batch 16 utterances per GPU, 128 text tokens, fixed 512 codes/utterance (10.2 s audio each,
+            163.5 s per step per GPU), prompt Tp = 689 frames, greedy decode with repetition penalty 10.
   vocoder   configs[1]: BigVGAN-only mel->wav, batch 8 of 80x800 mels per GPU (74.3 s audio / step / GPU)
-One process per GPU; utterance batches are sharded data-parallel (weak scaling: every rank gets its own
-batch); the only exchange step is the gather of waveforms to rank 0 over RCCL/xGMI.
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed) and `cpu_baseline`
-(the CPU oracle timed on this box's host cores on a bounded sample).
+One process per GPU; utterance batches shard data-parallel (weak scaling: every rank synthesises its own batch, full
+weight replica); exchange steps of the path: conditioning broadcast from rank 0 before, waveform gather to rank 0 after
+(RCCL over xGMI), nothing inside the hot loop.
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on its launch stream) and
+`cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample).
 """
 from __future__ import annotations
 
@@ -20,33 +24,184 @@ import json
 import os
 import sys
 import time
+import warnings
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "index-tts_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+MFMA_KERNELS = ("conv1d_mfma", "gemm_tn", "flash_attn")
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def roofline_from_profile(prof, steps):
+    tot_ms = sum(v["ms"] for v in prof.values())
+    for name, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+        log(f"[bench] kernel {name:22s} launches/step {v['launches'] // steps:6d}  {v['ms'] / steps:9.3f} ms/step "
+            f"({100 * v['ms'] / tot_ms:5.1f}%)  {v['flops'] / max(v['ms'], 1e-9) / 1e9:8.2f} TFLOP/s  "
+            f"{v['bytes'] / max(v['ms'], 1e-9) / 1e6:8.1f} GB/s(alg)")
+    dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    if dom_name.startswith(MFMA_KERNELS):
+        achieved = dom["flops"] / dom["ms"] / 1e9
+        r = {"kernel": dom_name, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+             "alg_flops_per_launch": dom["flops"] / dom["launches"]}
+    else:
+        achieved = dom["bytes"] / dom["ms"] / 1e6
+        r = {"kernel": dom_name, "bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+             "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None, "alg_bytes_per_launch": dom["bytes"] / dom["launches"]}
+    r["launches_per_step"] = dom["launches"] // steps
+    r["avg_launch_ms"] = round(dom["ms"] / dom["launches"], 4)
+    r["kernel_time_share"] = {k: round(v["ms"] / tot_ms, 4) for k, v in prof.items()}
+    r["kernel_ms_per_step"] = {k: round(v["ms"] / steps, 3) for k, v in prof.items()}
+    return r
+
+
+def cpu_threads():
+    # the box's CPU share, not the host's core count (oversubscribing a cgroup quota stalls for minutes)
+    return max(1, min(16, len(os.sched_getaffinity(0)), os.cpu_count() or 1))
+
+
+# ------------------------------------------------------------------------------------------------------
+def build_vocoder(args, world, rank, dev):
+    from indextts_amd import weights
+    from indextts_amd.config import BigVGANConfig
+    from indextts_amd.vocoder import BigVGAN
+    cfg = BigVGANConfig()
+    w = weights.synth_bigvgan_weights(cfg, tag="bench/bigvgan")
+    voc = BigVGAN(w, cfg)
+    B, Tm = args.batch or 8, args.frames
+    mel = torch.from_numpy(weights.synth_mel(f"bench/mel/rank{rank}", B, cfg.num_mels, Tm)).to(dev)
+    n_samples = Tm * cfg.total_upsample
+    gathered = [torch.empty(B, 1, n_samples, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        wav = voc(mel)
+        if world > 1:
+            dist.gather(wav, gathered, dst=0)
+        return wav
+
+    def profiled():
+        voc(mel)
+
+    def cpu_leg():
+        from oracle import vocoder as ov
+        cores = cpu_threads()
+        torch.set_num_threads(cores)
+        cmel = mel[:1].cpu()
+        wt = {k: torch.from_numpy(v) for k, v in w.items()}
+        with torch.no_grad():
+            ov.bigvgan_forward(wt, cfg, cmel[:, :, :32])
+            c0 = time.perf_counter()
+            cw = ov.bigvgan_forward(wt, cfg, cmel)
+            cdt = time.perf_counter() - c0
+        caudio = cw.shape[0] * cw.shape[-1] / cfg.sampling_rate
+        err = (voc(mel[:1].contiguous()).cpu() - cw).abs().max().item()
+        return {"value": round(caudio / cdt, 4), "unit": "audio_s/s", "cores": cores, "kind": "port",
+                "sample": f"oracle/vocoder.py BigVGAN fp32, 1 x [80 x {Tm}] mel of the same batch ({caudio:.2f} s audio)",
+                "max_abs_diff_vs_gpu": err}
+
+    desc = {"workload": f"configs[1]: BigVGAN-only mel->wav (bigvgan_v2_22khz_80band_256x, 112M params), batch {B} x [80 x {Tm}] "
+                        "mels per GPU", "batch_per_gpu": B, "mel_frames": Tm}
+    return step, profiled, cpu_leg, None, B * n_samples / cfg.sampling_rate, desc
+
+
+def build_pipeline(args, world, rank, dev):
+    from indextts_amd import synth, weights
+    from indextts_amd.config import PipelineConfig
+    from indextts_amd.dist import broadcast_conditioning, gather_waveforms
+    from indextts_amd.infer_v2 import IndexTTS2, PromptConditioning
+    cfg = PipelineConfig()
+    B, L, M, Tp = args.batch or 16, args.text_tokens, args.codes, args.prompt_frames
+    t0 = time.time()
+    wg = weights.synth_gpt_weights(cfg.gpt, tag="bench/gpt")
+    wg["mel_head.bias"][cfg.gpt.stop_mel_token] = -1e4      # fixed-length synthetic batches: never emit EOS -> exactly M codes
+    ws = weights.synth_s2mel_weights(cfg.s2mel, tag="bench/s2mel")
+    wv = weights.synth_bigvgan_weights(cfg.bigvgan, tag="bench/bigvgan")
+    log(f"[bench] rank {rank}: synthetic weights in {time.time() - t0:.1f}s")
+    tts = IndexTTS2.from_state_dicts(cfg, wg, ws, wv, device=dev)
+    cond0 = PromptConditioning.synthetic(cfg, prompt_frames=Tp, tag="bench/prompt")
+    shapes = cond0.shapes()
+    text = torch.from_numpy(synth.integers(f"bench/text/rank{rank}", (B, L), 2, cfg.gpt.number_text_tokens))
+    Tg = int(M * cfg.code_to_frame)
+    noise = torch.from_numpy(synth.uniform(f"bench/noise/rank{rank}", (B, cfg.s2mel.in_channels, Tp + Tg), 1.7)).to(dev)
+    cond_dev = cond0.to(dev)
+    audio_s = B * Tg * cfg.bigvgan.total_upsample / cfg.bigvgan.sampling_rate
+    warnings.filterwarnings("ignore", category=RuntimeWarning)
+
+    def step():
+        c = broadcast_conditioning(cond_dev if rank == 0 else None, shapes, dev) if world > 1 else cond_dev
+        wavs = tts.synthesize_batch(text, c, max_mel_tokens=M, noise=noise)
+        if world > 1:
+            gather_waveforms(wavs, dst=0)
+        return wavs[0]
+
+    def profiled():
+        tts.synthesize_batch(text, cond_dev, max_mel_tokens=M, noise=noise)
+
+    def stage_times():
+        tts.synthesize_batch(text, cond_dev, max_mel_tokens=M, noise=noise, sync_timers=True)
+        return dict(tts.last_stage_times)
+
+    def cpu_leg():
+        from oracle import pipeline as op
+        cores = cpu_threads()
+        torch.set_num_threads(cores)
+        Lc, Mc = 32, args.cpu_codes
+        ctext = text[:1, :Lc].clone()
+        Tgc = int(Mc * cfg.code_to_frame)
+        cnoise = noise[:1, :, : Tp + Tgc].cpu()
+        twg = {k: torch.from_numpy(v) for k, v in wg.items()}
+        tws = {k: torch.from_numpy(v) for k, v in ws.items()}
+        log(f"[bench] cpu baseline: oracle pipeline, 1 utterance, {Lc} text tokens, {Mc} codes, Tp={Tp}, "
+            f"{cfg.diffusion_steps} CFM steps, {cores} threads ...")
+        with torch.no_grad():
+            c0 = time.perf_counter()
+            r = op.synthesize_one(twg, tws, wv, cfg, ctext, cond0, cnoise, Mc)
+            cdt = time.perf_counter() - c0
+        caudio = r["wav"].shape[-1] / cfg.bigvgan.sampling_rate
+        wavs, mid = tts.synthesize_batch(ctext, cond_dev, max_mel_tokens=Mc, noise=cnoise.to(dev), return_intermediates=True)
+        codes_equal = bool(np.array_equal(mid["codes"][0].cpu().numpy(), r["codes"][0].numpy()))
+        mel_l1 = (mid["mel"][0].cpu() - r["mel"][0]).abs().mean().item()
+        wav_err = (wavs[0].cpu() - r["wav"]).abs().max().item() / 32767.0
+        log(f"[bench] cpu oracle: {caudio:.2f}s audio in {cdt:.1f}s; gpu-vs-cpu on that utterance: greedy codes equal={codes_equal}, "
+            f"mel L1={mel_l1:.2e}, max|wav| diff={wav_err:.2e} (full scale)")
+        return {"value": round(caudio / cdt, 4), "unit": "audio_s/s", "cores": cores, "kind": "port",
+                "sample": f"oracle/pipeline.py (fp32 torch CPU): 1 utterance, {Lc} text tokens, {Mc} codes ({caudio:.2f} s audio), "
+                          f"Tp={Tp}, {cfg.diffusion_steps} CFM steps, full-size weights",
+                "greedy_codes_equal_vs_gpu": codes_equal, "mel_l1_vs_gpu": mel_l1, "wav_max_abs_diff_vs_gpu_fullscale": wav_err}
+
+    desc = {"workload": f"configs[2]: IndexTTS-2 full pipeline (gpt 472M + s2mel 98M + BigVGAN 112M params), batch {B} utterances per "
+                        f"GPU, {L} text tokens, {M} codes ({Tg} mel frames, {audio_s / B:.2f} s) each, prompt {Tp} frames, "
+                        f"{cfg.diffusion_steps} CFM steps cfg {cfg.cfg_rate}, greedy decode rep-penalty 10",
+            "batch_per_gpu": B, "text_tokens": L, "codes": M, "prompt_frames": Tp, "diffusion_steps": cfg.diffusion_steps}
+    return step, profiled, cpu_leg, stage_times, audio_s, desc
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="vocoder", choices=["vocoder"])
-    ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--frames", type=int, default=800)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "vocoder"])
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--frames", type=int, default=800, help="vocoder workload: mel frames")
+    ap.add_argument("--text-tokens", type=int, default=128)
+    ap.add_argument("--codes", type=int, default=512)
+    ap.add_argument("--prompt-frames", type=int, default=689)
+    ap.add_argument("--cpu-codes", type=int, default=48, help="codes of the bounded CPU-baseline utterance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=1, help="batch rows of the workload the CPU baseline runs (bounded sample)")
+    ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -63,118 +218,72 @@ def main() -> int:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    from indextts_amd import _lib, weights
-    from indextts_amd.config import BigVGANConfig
-    from indextts_amd.vocoder import BigVGAN
-
+    from indextts_amd import _lib
     _lib.load()
-    cfg = BigVGANConfig()
     t0 = time.time()
-    w = weights.synth_bigvgan_weights(cfg, tag="bench/bigvgan")   # same random-init weights on every rank
-    voc = BigVGAN(w, cfg)
-    B, Tm = args.batch, args.frames
-    mel = torch.from_numpy(weights.synth_mel(f"bench/mel/rank{rank}", B, cfg.num_mels, Tm)).to(dev)
-    n_samples = Tm * cfg.total_upsample
-    audio_s_per_step_per_gpu = B * n_samples / cfg.sampling_rate
-    gathered = [torch.empty(B, 1, n_samples, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    build = build_pipeline if args.workload == "pipeline" else build_vocoder
+    step, profiled, cpu_leg, stage_times_fn, audio_s_per_step_per_gpu, desc = build(args, world, rank, dev)
     log(f"[bench] rank {rank}: model + inputs ready in {time.time() - t0:.1f}s")
-
-    def step():
-        wav = voc(mel)
-        if world > 1:   # the path's one exchange step: waveforms to rank 0 (north_star: "gather of waveforms")
-            dist.gather(wav, gathered, dst=0)
-        return wav
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
+        torch.cuda.synchronize()
+        log(f"[bench] rank {rank}: warmup {i + 1}/{args.warmup} done")
     barrier()
     t_start = time.perf_counter()
     for _ in range(args.steps):
-        wav = step()
+        out = step()
     barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    assert torch.isfinite(wav).all()
+    assert torch.isfinite(out).all()
+    log(f"[bench] rank {rank}: {args.steps} steps in {elapsed:.3f}s")
 
-    # ---- roofline leg: same steps again with per-launch HIP events (own stream = torch's current stream)
-    roofline = None
-    if rank == 0:
+    roofline = stages = None
+    if rank == 0 and not args.no_roofline:
+        # same work again with per-launch HIP events on the launch stream (graph replay is bypassed while profiling)
         _lib.profile_enable(True)
-        for _ in range(args.steps):
-            voc(mel)
+        nprof = min(args.steps, 2)
+        for _ in range(nprof):
+            profiled()
         torch.cuda.synchronize()
         prof = _lib.profile_read()
         _lib.profile_enable(False)
-        tot_ms = sum(v["ms"] for v in prof.values())
-        for name, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
-            log(f"[bench] kernel {name:22s} launches/step {v['launches'] // args.steps:4d}  "
-                f"{v['ms'] / args.steps:8.3f} ms/step ({100 * v['ms'] / tot_ms:5.1f}%)  "
-                f"{v['flops'] / v['ms'] / 1e9:8.2f} TFLOP/s  {v['bytes'] / v['ms'] / 1e6:8.1f} GB/s(alg)")
-        dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
-        if dom_name.startswith("conv1d_mfma"):
-            achieved = dom["flops"] / dom["ms"] / 1e9
-            roofline = {"kernel": dom_name, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                        "launches_per_step": dom["launches"] // args.steps,
-                        "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
-                        "alg_flops_per_launch": dom["flops"] / dom["launches"]}
-        else:
-            achieved = dom["bytes"] / dom["ms"] / 1e6
-            roofline = {"kernel": dom_name, "bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
-                        "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None,
-                        "launches_per_step": dom["launches"] // args.steps,
-                        "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
-                        "alg_bytes_per_launch": dom["bytes"] / dom["launches"]}
-        roofline["kernel_time_share"] = {k: round(v["ms"] / tot_ms, 4) for k, v in prof.items()}
+        roofline = roofline_from_profile(prof, nprof)
+        if stage_times_fn is not None:   # device-synchronised timers behind the reference's four stage names (infer_v2.py:895-901)
+            stages = {k: round(v, 4) for k, v in stage_times_fn().items()}
+            log(f"[bench] stage seconds (synchronised, one step): {stages}")
 
-    # ---- CPU baseline: the oracle (a port), on this box's host cores, bounded sample, rank 0 at N=1 only
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import vocoder as ov
-        # the box's CPU share, not the host's core count (oversubscribing a cgroup quota stalls for minutes)
-        cores = max(1, min(16, len(os.sched_getaffinity(0)), os.cpu_count() or 1))
-        torch.set_num_threads(cores)
-        rows = max(1, min(B, args.cpu_rows))
-        log(f"[bench] cpu baseline: oracle BigVGAN on [{rows},80,{Tm}] with {cores} threads ...")
-        cmel = mel[:rows].cpu()
-        wt = {k: torch.from_numpy(v) for k, v in w.items()}
-        with torch.no_grad():
-            ov.bigvgan_forward(wt, cfg, cmel[:, :, :32])   # warm the thread pool
-            c0 = time.perf_counter()
-            cw = ov.bigvgan_forward(wt, cfg, cmel)
-            cdt = time.perf_counter() - c0
-        caudio = cw.shape[0] * cw.shape[-1] / cfg.sampling_rate
-        # cross-check the GPU result on the same first row while we have it
-        gw = voc(mel[:rows].contiguous()).cpu()
-        err = (gw - cw).abs().max().item()
-        log(f"[bench] cpu oracle: {caudio:.2f}s audio in {cdt:.2f}s on {cores} threads; max|gpu-cpu| on that sample = {err:.2e}")
-        cpu_baseline = {"value": round(caudio / cdt, 4), "unit": "audio_s/s", "cores": cores, "kind": "port",
-                        "sample": f"oracle/vocoder.py BigVGAN fp32, {rows} x [80 x {Tm}] mels of the same batch ({caudio:.2f} s audio), "
-                                  f"torch CPU {cores} threads", "max_abs_diff_vs_gpu": err}
+        cpu_baseline = cpu_leg()
 
     if rank == 0:
         audio_total = audio_s_per_step_per_gpu * world * args.steps
         value = audio_total / elapsed
-        out = {
+        cfgd = dict(desc)
+        cfgd.update({"parallelism": f"dp{world}",
+                     "exchange": "broadcast(conditioning)+gather(waveforms)->rank0" if world > 1 else "none"})
+        res = {
             "metric": "synthesised audio seconds per second (IndexTTS-2 infer_v2 hot path), whole job",
             "value": round(value, 2), "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded random-init weights, log-mel-range inputs)",
-            "config": {"workload": "configs[1]: BigVGAN-only mel->wav (bigvgan_v2_22khz_80band_256x, 112M params), "
-                                   f"batch {B} x [80 x {Tm}] mels per GPU", "batch_per_gpu": B, "mel_frames": Tm,
-                       "parallelism": f"dp{world}", "exchange": "gather(waveforms)->rank0" if world > 1 else "none"},
-            "audio_s_per_s_per_gpu": round(value / world, 2), "rtf": round(elapsed / audio_total, 6),
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded random-init weights of the full architecture, synthetic prompt features and token ids)",
+            "config": cfgd, "audio_s_per_s_per_gpu": round(value / world, 2), "rtf": round(elapsed / audio_total, 6),
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(out), flush=True)
+        if stages:
+            res["stage_seconds"] = stages
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0

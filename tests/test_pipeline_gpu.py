@@ -25,7 +25,7 @@ def _build(device, eos_bias):
 
 def test_batch_equals_per_utterance_reference_flow(device):
     from oracle import pipeline as op
-    cfg, wg, ws, wv, tts, cond = _build(device, eos_bias=2.2)
+    cfg, wg, ws, wv, tts, cond = _build(device, eos_bias=6.5)
     B, L, MAXM = 4, 10, 24
     text = torch.from_numpy(synth.integers("t/pipe/text", (B, L), 2, cfg.gpt.number_text_tokens))
     lens = [10, 7, 10, 4]
@@ -58,7 +58,7 @@ def test_batch_equals_per_utterance_reference_flow(device):
 
 def test_infer_return_contract(device, tmp_path):
     from indextts_amd.infer_v2 import InferenceResult
-    cfg, wg, ws, wv, tts, cond = _build(device, eos_bias=2.2)
+    cfg, wg, ws, wv, tts, cond = _build(device, eos_bias=6.5)
     seg = synth.integers("t/pipe/seg", (2, 6), 2, cfg.gpt.number_text_tokens).tolist()
     sr, wav = tts.infer(cond, seg, None, max_mel_tokens=16)
     assert sr == 22050 and wav.dtype == np.int16 and wav.ndim == 2 and wav.shape[1] == 1
