@@ -35,8 +35,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
   float* knew = sm + 64;     // [64]
   float* vnew = sm + 128;    // [64]
   float* red = sm + 192;     // [8]
-  float* outp = sm + 256;    // [4][64]
-  float* pr = sm + 512;      // [Smax] scores / probabilities
+  float* outp = sm + 256;    // [16][64] per-key-group partial outputs
+  float* pr = sm + 256 + 1024;   // [Smax] scores / probabilities
 
   const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int pos = p.st->pos;                  // index of the token being processed = keys already cached
@@ -44,20 +44,22 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
   float* kc = p.kcache + (size_t)(b * p.H + h) * 16 * Smax * 4;
   float* vc = p.vcache + (size_t)(b * p.H + h) * Smax * 64;
 
-  if (tid < 64) {
-    const int col = h * 64 + tid;
-    float q = p.qkv_bias[col], k = p.qkv_bias[d + col], v = p.qkv_bias[2 * d + col];
-    for (int s = 0; s < p.parts; ++s) {
-      const float* row = p.qkv_part + ((size_t)s * p.part_rows + b) * 3 * d;
-      q += row[col];
-      k += row[d + col];
-      v += row[2 * d + col];
+  // ---- q, k, v of the new token: bias + split-K slab sum (waves 0,1,2 take q,k,v; loads of all slabs in flight together) ----
+  if (tid < 192) {
+    const int which = tid >> 6, dd = tid & 63;
+    const int col = which * d + h * 64 + dd;
+    const float* row = p.qkv_part + (size_t)b * 3 * d + col;
+    const size_t sst = (size_t)p.part_rows * 3 * d;
+    float acc = p.qkv_bias[col];
+    int s = 0;
+    for (; s + 4 <= p.parts; s += 4) {
+      const float t0 = row[(size_t)(s + 0) * sst], t1 = row[(size_t)(s + 1) * sst], t2 = row[(size_t)(s + 2) * sst], t3 = row[(size_t)(s + 3) * sst];
+      acc = (((acc + t0) + t1) + t2) + t3;
     }
-    qs[tid] = q * p.scale;
-    knew[tid] = k;
-    vnew[tid] = v;
-    kc[((size_t)(tid >> 2) * Smax + pos) * 4 + (tid & 3)] = k;
-    vc[(size_t)pos * 64 + tid] = v;
+    for (; s < p.parts; ++s) acc += row[(size_t)s * sst];
+    if (which == 0) qs[dd] = acc * p.scale;
+    else if (which == 1) { knew[dd] = acc; kc[((size_t)(dd >> 2) * Smax + pos) * 4 + (dd & 3)] = acc; }
+    else { vnew[dd] = acc; vc[(size_t)pos * 64 + dd] = acc; }
   }
   __syncthreads();
 
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
 #pragma unroll
   for (int i = 0; i < 16; ++i) q4[i] = *reinterpret_cast<const f32x4*>(&qs[4 * i]);
 
-  // ---- scores ----
+  // ---- scores: one key per thread (16 coalesced 16-byte loads each) ----
   float mx = -1e30f;
   for (int s = ks + tid; s <= pos; s += 256) {
     float dot = 0.f;
@@ -101,25 +103,31 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
   __syncthreads();
   const float l = red[4] + red[5] + red[6] + red[7];
 
-  // ---- P.V : wave w takes keys ks+w, ks+w+4, ... ; lane = head dim ----
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int s = ks + wave;
-  for (; s + 12 < pos; s += 16) {
-    const float v0 = vc[(size_t)s * 64 + lane], v1 = vc[(size_t)(s + 4) * 64 + lane];
-    const float v2 = vc[(size_t)(s + 8) * 64 + lane], v3 = vc[(size_t)(s + 12) * 64 + lane];
-    a0 = fmaf(pr[s], v0, a0);
-    a1 = fmaf(pr[s + 4], v1, a1);
-    a2 = fmaf(pr[s + 8], v2, a2);
-    a3 = fmaf(pr[s + 12], v3, a3);
+  // ---- P.V : 16 key groups x 16 lanes; a lane owns 4 head dims (one 16-byte load per key, 256-byte rows coalesced),
+  //      4 keys in flight per lane; group g takes keys ks+g, ks+g+16, ... ----
+  const int grp = tid >> 4, l16 = tid & 15;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  int s = ks + grp;
+  for (; s + 48 < pos; s += 64) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(vc + (size_t)s * 64 + 4 * l16);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(vc + (size_t)(s + 16) * 64 + 4 * l16);
+    const f32x4 v2 = *reinterpret_cast<const f32x4*>(vc + (size_t)(s + 32) * 64 + 4 * l16);
+    const f32x4 v3 = *reinterpret_cast<const f32x4*>(vc + (size_t)(s + 48) * 64 + 4 * l16);
+    a0 += pr[s] * v0;
+    a1 += pr[s + 16] * v1;
+    a2 += pr[s + 32] * v2;
+    a3 += pr[s + 48] * v3;
   }
-  for (; s <= pos; s += 4) {
-    const float vv = (s == pos) ? vnew[lane] : vc[(size_t)s * 64 + lane];
-    a0 = fmaf(pr[s], vv, a0);
+  for (; s <= pos; s += 16) {
+    const f32x4 vv = (s == pos) ? *reinterpret_cast<const f32x4*>(&vnew[4 * l16]) : *reinterpret_cast<const f32x4*>(vc + (size_t)s * 64 + 4 * l16);
+    a0 += pr[s] * vv;
   }
-  outp[wave * 64 + lane] = (a0 + a1) + (a2 + a3);
+  *reinterpret_cast<f32x4*>(&outp[grp * 64 + 4 * l16]) = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (tid < 64) {
-    const float o = (outp[tid] + outp[64 + tid]) + (outp[128 + tid] + outp[192 + tid]);
+    float o = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) o += outp[g * 64 + tid];
     p.out[(size_t)b * d + h * 64 + tid] = l > 0.f ? o / l : 0.f;
   }
 }
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
 int decode_attn_forward(const DecodeAttnArgs& a, hipStream_t stream) {
   IDX_CHECK(a.qkv_part && a.qkv_bias && a.kcache && a.vcache && a.out && a.st, "null pointer");
   IDX_CHECK(a.d == a.H * 64, "head_dim must be 64");
-  const size_t lds = (size_t)(512 + a.Smax) * sizeof(float);
+  const size_t lds = (size_t)(256 + 1024 + a.Smax) * sizeof(float);
   IDX_CHECK(lds <= 160 * 1024, "Smax too large for the LDS score buffer");
   static bool attr_set = false;
   if (!attr_set) {
@@ -150,12 +158,31 @@ __global__ __launch_bounds__(256) void sample_greedy_kernel(const SampleArgs p) 
   float best = -INFINITY;
   int bidx = 0x7fffffff;
   const unsigned char* seen = p.seen + (size_t)b * V;
-  for (int v = tid; v < V; v += 256) {
-    float l = p.bias ? p.bias[v] : 0.0f;
-    for (int s = 0; s < p.parts; ++s) l += p.part[((size_t)s * p.part_rows + b) * V + v];
-    if (p.logits_out) p.logits_out[(size_t)b * V + v] = l;
-    if (seen[v]) l = l < 0.f ? l * p.penalty : l / p.penalty;
-    if (l > best) { best = l; bidx = v; }        // ascending v per thread: strict > keeps the first maximum
+  const size_t sst = (size_t)p.part_rows * V;
+  const float* prow = p.part + (size_t)b * V;
+  for (int v0 = tid; v0 < V; v0 += 1024) {       // 4 vocabulary entries per trip, all their slab loads in flight together
+    float l4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int v = v0 + 256 * u;
+      l4[u] = (v < V && p.bias) ? p.bias[v] : 0.0f;
+    }
+    for (int s = 0; s < p.parts; ++s) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int v = v0 + 256 * u;
+        if (v < V) l4[u] += prow[(size_t)s * sst + v];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int v = v0 + 256 * u;
+      if (v >= V) continue;
+      float l = l4[u];
+      if (p.logits_out) p.logits_out[(size_t)b * V + v] = l;
+      if (seen[v]) l = l < 0.f ? l * p.penalty : l / p.penalty;
+      if (l > best) { best = l; bidx = v; }      // ascending v per thread: strict > keeps the first maximum
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {

@@ -70,6 +70,19 @@ __global__ __launch_bounds__(256) void gemv16_kernel(const GemvKP p) {
   const int nch = min(p.chunks_per_slice, p.kc16 - c0);
   const int k0 = c0 * 16, kslice = nch * 16;
 
+  constexpr int UN = 8;   // weight loads in flight per wave (8 KiB)
+  const int nt = blockIdx.x * 4 + wave;
+  const bool wave_ok = nt < p.ntiles;
+  const float* wbase = p.wp + ((size_t)(wave_ok ? nt : 0) * p.kc16 + c0) * 256 + lane * 4;
+  // the weights do not depend on the activations: put the first 8 KiB per wave in flight BEFORE staging x, so the
+  // two HBM round trips of this (microseconds-short) kernel overlap instead of adding up
+  f32x4 wpre[UN];
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    wpre[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (wave_ok && u < nch) wpre[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wbase + (size_t)u * 256));
+  }
+
   // ---- stage activations: element (row, k) -> A-fragment slot [(k/16)][row/16][ (k%16)/4 *16 + row%16 ][k%4] ----
   const int q4n = kslice >> 2;
   for (int idx = tid; idx < MT * 16 * q4n; idx += 256) {
@@ -79,8 +92,15 @@ __global__ __launch_bounds__(256) void gemv16_kernel(const GemvKP p) {
     if (row < p.rows && k < p.K) {
       if (p.xpart) {
         f32x4 a = p.xbias ? *reinterpret_cast<const f32x4*>(p.xbias + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < p.xparts; ++s)
-          a += *reinterpret_cast<const f32x4*>(p.xpart + ((size_t)s * p.xpart_rows + row) * p.ld_xpart + k);
+        const float* xp = p.xpart + (size_t)row * p.ld_xpart + k;
+        const size_t sst = (size_t)p.xpart_rows * p.ld_xpart;
+        int s = 0;
+        for (; s + 4 <= p.xparts; s += 4) {
+          const f32x4 t0 = *reinterpret_cast<const f32x4*>(xp + (size_t)(s + 0) * sst), t1 = *reinterpret_cast<const f32x4*>(xp + (size_t)(s + 1) * sst);
+          const f32x4 t2 = *reinterpret_cast<const f32x4*>(xp + (size_t)(s + 2) * sst), t3 = *reinterpret_cast<const f32x4*>(xp + (size_t)(s + 3) * sst);
+          a = (((a + t0) + t1) + t2) + t3;
+        }
+        for (; s < p.xparts; ++s) a += *reinterpret_cast<const f32x4*>(xp + (size_t)s * sst);
         if (p.xact == 1) { a[0] = gelu_new_f(a[0]); a[1] = gelu_new_f(a[1]); a[2] = gelu_new_f(a[2]); a[3] = gelu_new_f(a[3]); }
         v = a;
       } else {
@@ -92,16 +112,42 @@ __global__ __launch_bounds__(256) void gemv16_kernel(const GemvKP p) {
   }
   __syncthreads();
 
-  const int nt = blockIdx.x * 4 + wave;
-  if (nt >= p.ntiles) return;
+  if (!wave_ok) return;
   typedef float f32x4v __attribute__((ext_vector_type(4)));
   f32x4v acc[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  const float* wbase = p.wp + ((size_t)nt * p.kc16 + c0) * 256 + lane * 4;
 
-  constexpr int UN = 8;   // weight loads in flight per wave (8 KiB)
-  int c = 0;
+  // second batch in flight while the first is consumed
+  f32x4 wnext[UN];
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    wnext[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (UN + u < nch) wnext[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wbase + (size_t)(UN + u) * 256));
+  }
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    if (u < nch) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(&xs[((u * MT + mt) * 64 + lane) * 4]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s], wpre[u][s], acc[mt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    if (UN + u < nch) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(&xs[(((UN + u) * MT + mt) * 64 + lane) * 4]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s], wnext[u][s], acc[mt], 0, 0, 0);
+      }
+    }
+  }
+  int c = 2 * UN;
   for (; c + UN <= nch; c += UN) {
     f32x4 w[UN];
 #pragma unroll

@@ -58,10 +58,43 @@ __global__ __launch_bounds__(256) void rows_norm_kernel(const RowsNormArgs p) {
     if (e < d) {
       if (xin) a = xin[e];
       if (p.add_bias) a += p.add_bias[e];
-      for (int s = 0; s < p.num_partials; ++s) a += p.partials[((size_t)s * p.partial_rows + m) * p.ld_partial + e];
-      if (p.x_out) p.x_out[(size_t)m * p.ld_out + e] = a;
     }
     v[i] = a;
+  }
+  if (p.num_partials > 0) {
+    // split-K slabs: every trip issues 4 x NPER independent loads before the adds (the decode step has only
+    // `rows` workgroups in flight, so memory-level parallelism has to come from inside the thread)
+    const float* pbase = p.partials + (size_t)m * p.ld_partial;
+    const size_t sstride = (size_t)p.partial_rows * p.ld_partial;
+    int s = 0;
+    for (; s + 4 <= p.num_partials; s += 4) {
+      float t0[NPER], t1[NPER], t2[NPER], t3[NPER];
+#pragma unroll
+      for (int i = 0; i < nper; ++i) {
+        const int e = tid + (i << 8);
+        const bool ok = e < d;
+        t0[i] = ok ? pbase[(size_t)(s + 0) * sstride + e] : 0.f;
+        t1[i] = ok ? pbase[(size_t)(s + 1) * sstride + e] : 0.f;
+        t2[i] = ok ? pbase[(size_t)(s + 2) * sstride + e] : 0.f;
+        t3[i] = ok ? pbase[(size_t)(s + 3) * sstride + e] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < nper; ++i) v[i] = (((v[i] + t0[i]) + t1[i]) + t2[i]) + t3[i];
+    }
+    for (; s < p.num_partials; ++s) {
+#pragma unroll
+      for (int i = 0; i < nper; ++i) {
+        const int e = tid + (i << 8);
+        if (e < d) v[i] += pbase[(size_t)s * sstride + e];
+      }
+    }
+  }
+  if (p.x_out) {
+#pragma unroll
+    for (int i = 0; i < nper; ++i) {
+      const int e = tid + (i << 8);
+      if (e < d) p.x_out[(size_t)m * p.ld_out + e] = v[i];
+    }
   }
   if (p.mode == NORM_NONE || !p.y) {
     if (p.y)
