@@ -44,7 +44,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def roofline_from_profile(prof, steps):
+def roofline_from_profile(prof, steps, workload="pipeline"):
     tot_ms = sum(v["ms"] for v in prof.values())
     for name, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
         log(f"[bench] kernel {name:22s} launches/step {v['launches'] // steps:6d}  {v['ms'] / steps:9.3f} ms/step "
@@ -60,6 +60,16 @@ def roofline_from_profile(prof, steps):
         achieved = dom["bytes"] / dom["ms"] / 1e6
         r = {"kernel": dom_name, "bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
              "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None, "alg_bytes_per_launch": dom["bytes"] / dom["launches"]}
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (separate --pmc FETCH_SIZE /
+    # WRITE_SIZE runs, gfx950 correction applied; profiles/README.md) -- null when no pass is on file for this kernel
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_r01.json")) as f:
+            tr = json.load(f)["kernels"].get(dom_name)
+        if tr and workload == "pipeline":
+            r["traffic"] = tr["hbm_bytes_per_launch"]
+            r["traffic_source"] = "profiles/traffic_r01.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes = (2*FETCH+WRITE)*1024)"
+    except (OSError, KeyError, ValueError):
+        pass
     r["launches_per_step"] = dom["launches"] // steps
     r["avg_launch_ms"] = round(dom["ms"] / dom["launches"], 4)
     r["kernel_time_share"] = {k: round(v["ms"] / tot_ms, 4) for k, v in prof.items()}
@@ -199,7 +209,7 @@ def main() -> int:
     ap.add_argument("--text-tokens", type=int, default=128)
     ap.add_argument("--codes", type=int, default=512)
     ap.add_argument("--prompt-frames", type=int, default=689)
-    ap.add_argument("--cpu-codes", type=int, default=48, help="codes of the bounded CPU-baseline utterance")
+    ap.add_argument("--cpu-codes", type=int, default=96, help="codes of the bounded CPU-baseline utterance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -257,7 +267,7 @@ def main() -> int:
         torch.cuda.synchronize()
         prof = _lib.profile_read()
         _lib.profile_enable(False)
-        roofline = roofline_from_profile(prof, nprof)
+        roofline = roofline_from_profile(prof, nprof, args.workload)
         if stage_times_fn is not None:   # device-synchronised timers behind the reference's four stage names (infer_v2.py:895-901)
             stages = {k: round(v, 4) for k, v in stage_times_fn().items()}
             log(f"[bench] stage seconds (synchronised, one step): {stages}")
