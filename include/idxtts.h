@@ -96,7 +96,13 @@ typedef struct idxtts_linear idxtts_linear;
 int idxtts_linear_create(const float* weight, const float* bias /* may be NULL */, int N, int K, int weight_is_kn,
                          idxtts_linear** out);
 int idxtts_linear_fwd(const idxtts_linear* lin, const float* x, int ldx, float* y, int ldy, const float* residual /* may be NULL */,
-                      int ldr, int M, int act, void* stream);
+                      int ldr, int M, int act, int bf16x3 /* 0: exact fp32 MFMA, 1: split-bf16 (3 bf16 MFMAs per product) */,
+                      void* stream);
+/* Arithmetic of the GEMM-shaped passes of the model contexts (s2mel, GPT latent pass): 0 = exact fp32 MFMA,
+ * 1 (default) = split-bf16: x*w ~= hi*hi' + hi*lo' + lo*hi' on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+ * (relative product error ~2^-16).  The KV-cached greedy decode and its prefill are always exact fp32. */
+int idxtts_set_gemm_mode(int mode);
+int idxtts_get_gemm_mode(void);
 int idxtts_linear_destroy(idxtts_linear* lin);
 /* Multi-head attention, head_dim 64, softmax(q k^T * scale + mask) v without materialising the scores.
  * q/k/v/o are read in place: element (b, t, h, e) at base + b*batch_stride + t*token_stride + 64*h + e.

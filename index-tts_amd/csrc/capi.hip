@@ -194,6 +194,17 @@ int idxtts_linear_create(const float* weight, const float* bias, int N, int K, i
   float* d = nullptr;
   if (l->arena.upload(packed.data(), packed.size(), &d)) return 1;
   l->w.wp = d; l->w.N = N; l->w.K = K;
+  {
+    std::vector<float> wnk(hw);
+    if (weight_is_kn)
+      for (int k = 0; k < K; ++k)
+        for (int n = 0; n < N; ++n) wnk[(size_t)n * K + k] = hw[(size_t)k * N + n];
+    std::vector<float> p16((linear_bf16x3_packed_bytes(N, K) + 3) / 4);
+    pack_linear_bf16x3(p16.data(), wnk.data(), N, K);
+    float* d16 = nullptr;
+    if (l->arena.upload(p16.data(), p16.size(), &d16)) return 1;
+    l->w.wp16 = d16;
+  }
   if (bias) {
     if (fetch(bias, N, &hb)) return 1;
     if (l->arena.upload(hb.data(), hb.size(), &d)) return 1;
@@ -205,12 +216,12 @@ int idxtts_linear_create(const float* weight, const float* bias, int N, int K, i
 }
 
 int idxtts_linear_fwd(const idxtts_linear* lin, const float* x, int ldx, float* y, int ldy, const float* residual, int ldr, int M,
-                      int act, void* stream) {
+                      int act, int bf16x3, void* stream) {
   API_BEGIN
   IDX_CHECK(lin, "null handle");
   GemmArgs a;
   a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.res = residual; a.ldr = ldr; a.M = M; a.act = act;
-  return gemm_tn_forward(lin->w, a, static_cast<hipStream_t>(stream));
+  return bf16x3 ? gemm_bf16x3_forward(lin->w, a, static_cast<hipStream_t>(stream)) : gemm_tn_forward(lin->w, a, static_cast<hipStream_t>(stream));
   API_END
 }
 
@@ -336,5 +347,13 @@ int idxtts_s2mel_cfm(idxtts_ctx* ctx, const float* mu, const int* x_lens, const 
                 workspace_bytes, static_cast<hipStream_t>(stream));
   API_END
 }
+
+
+int idxtts_set_gemm_mode(int mode) {
+  set_gemm_mode(mode);
+  return 0;
+}
+
+int idxtts_get_gemm_mode(void) { return get_gemm_mode(); }
 
 }  // extern "C"

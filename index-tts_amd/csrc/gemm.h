@@ -10,6 +10,7 @@ struct LinearWeights {      // device-resident, packed for the MFMA B operand
   const float* wp = nullptr;   // [ceil(N/32)][ceil(K/16)][g2][h2][j32][4]
   const float* bias = nullptr; // [N] (for SWIGLU: [N] in packed row order) or null
   int N = 0, K = 0;
+  const void* wp16 = nullptr;  // optional split-bf16 pack [N/128][K/32][hl][128][40] bf16 (gemm_bf16x3.hip)
 };
 
 static inline size_t linear_packed_floats(int N, int K) { return (size_t)cdiv(N, 32) * cdiv(K, 16) * 512; }
@@ -34,6 +35,17 @@ struct GemmArgs {
   const int* row_len = nullptr;
 };
 
-int gemm_tn_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t stream);
+int gemm_tn_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t stream);      // exact fp32 MFMA
+int gemm_bf16x3_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t stream);  // split-bf16 (3 bf16 MFMAs / product)
+size_t linear_bf16x3_packed_bytes(int N, int K);
+void pack_linear_bf16x3(void* dst, const float* w, int N, int K);
+
+// Arithmetic of the GEMM-shaped (compute-bound) passes: GEMM_F32 = exact fp32 MFMA everywhere; GEMM_BF16X3 = split-bf16
+// for launches with M >= 256 whose weights carry a bf16 pack (s2mel, GPT latent pass).  Decode GEMVs are always fp32.
+enum GemmMode { GEMM_F32 = 0, GEMM_BF16X3 = 1 };
+void set_gemm_mode(int mode);
+int get_gemm_mode();
+// dispatches on the mode above
+int gemm_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t stream);
 
 }  // namespace idxtts

@@ -19,7 +19,7 @@
 #include <algorithm>
 #include <cmath>
 
-#include "gemm.h"
+#include "gemm_common.h"
 #include "prof.h"
 
 namespace idxtts {
@@ -54,40 +54,21 @@ void pack_linear_kn(float* dst, const float* w_kn, int K, int N) {
     }
 }
 
-struct GemmKP {
-  const float* x; const float* wp; const float* bias; const float* res; float* y;
-  int M, N, K, ldx, ldy, ldr;
-  int kc16;        // 16-wide K chunks in the packed weights
-  int mtiles, mt8; // 128-row tiles, ceil(mtiles/8)
-  int act;
-  float out_scale;
-  int taps, kc, seq_len, dil, pad_left, pad_mode;
-  const int* row_len;
-};
-
 constexpr int XBLK = 132;   // floats per padded [32 rows][4] sub-block (528 B)
-
-__device__ __forceinline__ float act_apply(float v, int act) {
-  if (act == ACT_GELU_NEW) {
-    const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
-    return 0.5f * v * (1.0f + tanhf(u));
-  }
-  if (act == ACT_SILU) return v / (1.0f + expf(-v));
-  if (act == ACT_MISH) {   // x * tanh(softplus(x)), softplus threshold 20 as torch
-    const float sp = v > 20.0f ? v : log1pf(expf(v));
-    return v * tanhf(sp);
-  }
-  return v;
-}
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmKP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float (*Xs)[4 * 2 * 4 * XBLK] = reinterpret_cast<float (*)[4 * 2 * 4 * XBLK]>(smem);
   float (*Ws)[4 * 2 * 512] = reinterpret_cast<float (*)[4 * 2 * 512]>(smem + 2 * 4 * 2 * 4 * XBLK);
 
+  // XCD x owns the m-tiles == x (mod 8).  Walk order inside an XCD:
+  //   n_fast = 1 (weights fit the 4 MiB L2): all n-blocks of one m-tile back to back -> the activation tile is fetched
+  //              from HBM once and W stays L2-resident (DiT / WaveNet shapes: W <= 6 MB, X = 100+ MB)
+  //   n_fast = 0 (big W, few rows: GPT prefill): all m-tiles of one n-block back to back -> W streams once per XCD
   const int L = blockIdx.x, xcd = L & 7, q = L >> 3;
-  const int bn = q / p.mt8;
-  const int bm = (q - bn * p.mt8) * 8 + xcd;
+  int bn, bm;
+  if (p.n_fast) { const int bml = q / p.nblocks; bn = q - bml * p.nblocks; bm = bml * 8 + xcd; }
+  else { bn = q / p.mt8; bm = (q - bn * p.mt8) * 8 + xcd; }
   if (bm >= p.mtiles) return;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -186,50 +167,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmKP p) {
     __syncthreads();
   }
 
-  // ---- epilogue ----
-  auto row_masked = [&](int m) -> bool {
-    if (!p.row_len) return false;
-    const int sb = m / p.seq_len;
-    return (m - sb * p.seq_len) >= p.row_len[sb];
-  };
-  if (p.act == ACT_SWIGLU || p.act == ACT_GATE) {
-    // packed rows alternate [32 of w1 | 32 of w3]: acc[.][0] is the gate, acc[.][1] the linear branch
-    const int n0 = bn * 128 + wn * 64 + j;            // packed column of the gate
-    const int no = bn * 64 + wn * 32 + j;             // output column
-    const bool ok = (bn * 128 + wn * 64) < p.N;       // N % 64 == 0: a wave's 64 packed columns are all in or all out
-    const float b0 = (p.bias && ok) ? p.bias[n0] : 0.0f, b1 = (p.bias && ok) ? p.bias[n0 + 32] : 0.0f;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = bm * 128 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= p.M || !ok) continue;
-        const float gte = acc[mt][0][r] + b0, lin = acc[mt][1][r] + b1;
-        float v = p.act == ACT_SWIGLU ? (gte / (1.0f + expf(-gte))) * lin : tanhf(gte) * (1.0f / (1.0f + expf(-lin)));
-        v *= p.out_scale;
-        if (p.res) v += p.res[(size_t)m * p.ldr + no];
-        if (row_masked(m)) v = 0.0f;
-        p.y[(size_t)m * p.ldy + no] = v;
-      }
-    return;
-  }
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int n = bn * 128 + wn * 64 + nt * 32 + j;
-    if (n >= p.N) continue;
-    const float bias = p.bias ? p.bias[n] : 0.0f;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = bm * 128 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= p.M) continue;
-        float v = act_apply(acc[mt][nt][r] + bias, p.act) * p.out_scale;
-        if (p.res) v += p.res[(size_t)m * p.ldr + n];
-        if (row_masked(m)) v = 0.0f;
-        p.y[(size_t)m * p.ldy + n] = v;
-      }
-  }
+  gemm_epilogue(p, acc, bm, bn, wm, wn, h, j);
 }
 
 int gemm_tn_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t stream) {
@@ -254,6 +192,8 @@ int gemm_tn_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t strea
   p.taps = a.taps; p.kc = w.K / std::max(1, a.taps); p.seq_len = a.seq_len > 0 ? a.seq_len : 1; p.dil = a.dil; p.pad_left = a.pad_left;
   p.pad_mode = a.pad_mode; p.row_len = a.row_len;
   const int nblocks = cdiv(w.N, 128);
+  p.nblocks = nblocks;
+  p.n_fast = ((double)w.N * w.K * 4.0 <= 8.0 * 1024 * 1024) && ((double)a.M * w.K > (double)w.N * w.K) ? 1 : 0;
   const int64_t grid = (int64_t)8 * nblocks * p.mt8;
   IDX_CHECK(grid < (1ll << 31), "grid size");
   const double flops = 2.0 * a.M * (double)w.N * w.K;
@@ -268,6 +208,15 @@ int gemm_tn_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t strea
   hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)grid), dim3(256), lds, stream, p);
   IDX_LAUNCH_CHECK();
   return 0;
+}
+
+static int g_gemm_mode = GEMM_BF16X3;
+void set_gemm_mode(int mode) { g_gemm_mode = mode == GEMM_F32 ? GEMM_F32 : GEMM_BF16X3; }
+int get_gemm_mode() { return g_gemm_mode; }
+
+int gemm_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t stream) {
+  if (g_gemm_mode == GEMM_BF16X3 && w.wp16 && a.M >= 256) return gemm_bf16x3_forward(w, a, stream);
+  return gemm_tn_forward(w, a, stream);
 }
 
 }  // namespace idxtts

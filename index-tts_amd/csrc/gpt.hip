@@ -57,6 +57,16 @@ static int make_proj(std::map<std::string, HostTensor>& t, DeviceArena& arena, c
   if (arena.upload(buf.data(), buf.size(), &d)) return 1;
   lw->wp = d; lw->N = N; lw->K = K;
   if (upload(t, arena, prefix + ".bias", {N}, &lw->bias)) return 1;
+  {   // split-bf16 copy, used by the latent pass only (the KV-cache-building prefill stays exact fp32)
+    std::vector<float> wt((size_t)N * K);
+    for (int k = 0; k < K; ++k)
+      for (int n = 0; n < N; ++n) wt[(size_t)n * K + k] = w->data[(size_t)k * N + n];
+    std::vector<float> p16((linear_bf16x3_packed_bytes(N, K) + 3) / 4);
+    pack_linear_bf16x3(p16.data(), wt.data(), N, K);
+    float* d16 = nullptr;
+    if (arena.upload(p16.data(), p16.size(), &d16)) return 1;
+    lw->wp16 = d16;
+  }
   buf.assign(gemv16_packed_floats(N, K), 0.0f);
   pack_gemv16_kn(buf.data(), w->data.data(), K, N);
   if (arena.upload(buf.data(), buf.size(), &d)) return 1;
@@ -152,6 +162,8 @@ size_t GPTModel::workspace_bytes(int B, int S, int max_new) const { return carve
 
 // one transformer layer over M = B*S token rows (prefill / latent pass)
 int GPTModel::layer_full(int li, const Buffers& w, int B, int S, const int* kstart, bool store_kv, hipStream_t st) {
+  // prefill (store_kv) feeds the greedy decode: exact fp32.  Latent pass: mode-dependent (split-bf16 by default).
+  auto mm = [&](const LinearWeights& lw, const GemmArgs& ga) { return store_kv ? gemm_tn_forward(lw, ga, st) : gemm_forward(lw, ga, st); };
   const GPTLayer& L = layers[li];
   const int d = cfg.model_dim, M = B * S;
   RowsNormArgs n1;
@@ -159,7 +171,7 @@ int GPTModel::layer_full(int li, const Buffers& w, int B, int S, const int* ksta
   if (rows_norm_forward(n1, st)) return 1;
   GemmArgs g;
   g.x = w.h; g.ldx = d; g.y = w.qkv; g.ldy = 3 * d; g.M = M;
-  if (gemm_tn_forward(L.attn_l, g, st)) return 1;
+  if (mm(L.attn_l, g)) return 1;
   if (store_kv) {
     const size_t per_layer = (size_t)B * cfg.heads * w.Smax * 64;
     if (kv_store_prefill(w.qkv, w.kcache + li * per_layer, w.vcache + li * per_layer, B, cfg.heads, S, w.Smax, d, st)) return 1;
@@ -172,16 +184,16 @@ int GPTModel::layer_full(int li, const Buffers& w, int B, int S, const int* ksta
   if (flash_attn_forward(a, st)) return 1;
   GemmArgs p;
   p.x = w.att; p.ldx = d; p.y = w.x; p.ldy = d; p.res = w.x; p.ldr = d; p.M = M;
-  if (gemm_tn_forward(L.proj_l, p, st)) return 1;
+  if (mm(L.proj_l, p)) return 1;
   RowsNormArgs n2 = n1;
   n2.g1 = L.ln2_g; n2.b1 = L.ln2_b;
   if (rows_norm_forward(n2, st)) return 1;
   GemmArgs f1;
   f1.x = w.h; f1.ldx = d; f1.y = w.ff; f1.ldy = 4 * d; f1.M = M; f1.act = ACT_GELU_NEW;
-  if (gemm_tn_forward(L.fc_l, f1, st)) return 1;
+  if (mm(L.fc_l, f1)) return 1;
   GemmArgs f2;
   f2.x = w.ff; f2.ldx = 4 * d; f2.y = w.x; f2.ldy = d; f2.res = w.x; f2.ldr = d; f2.M = M;
-  if (gemm_tn_forward(L.fc2_l, f2, st)) return 1;
+  if (mm(L.fc2_l, f2)) return 1;
   return 0;
 }
 

@@ -54,6 +54,13 @@ int make_linear(DeviceArena& arena, const std::vector<float>& w, const std::vect
   pack_linear(packed.data(), w.data(), N, K);
   if (up(arena, packed, &out->wp)) return 1;
   out->N = N; out->K = K;
+  {   // split-bf16 copy for the M >= 256 launches (gemm_bf16x3.hip)
+    std::vector<float> p16((linear_bf16x3_packed_bytes(N, K) + 3) / 4);
+    pack_linear_bf16x3(p16.data(), w.data(), N, K);
+    const float* d16 = nullptr;
+    if (up(arena, p16, &d16)) return 1;
+    out->wp16 = d16;
+  }
   if (bias && up(arena, *bias, &out->bias)) return 1;
   return 0;
 }
@@ -312,7 +319,7 @@ static int gemm(const LinearWeights& w, const float* x, int ldx, float* y, int l
                 const float* res = nullptr, int ldr = 0) {
   GemmArgs a;
   a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.M = M; a.act = act; a.res = res; a.ldr = ldr;
-  return gemm_tn_forward(w, a, st);
+  return gemm_forward(w, a, st);
 }
 
 static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipStream_t st) {
@@ -371,17 +378,17 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
     GemmArgs g;
     g.x = w.wn_x; g.ldx = Wh; g.y = w.wn_acts; g.ldy = Wh; g.M = M; g.act = ACT_GATE;
     g.taps = k; g.seq_len = T; g.dil = dil; g.pad_left = (k - 1) / 2 * dil; g.pad_mode = 1; g.row_len = w.lens2;
-    if (gemm_tn_forward(in, g, st)) return 1;
+    if (gemm_forward(in, g, st)) return 1;
     if (W.has_res) {   // x = (x + res) * mask
       GemmArgs r;
       r.x = w.wn_acts; r.ldx = Wh; r.y = w.wn_x; r.ldy = Wh; r.res = w.wn_x; r.ldr = Wh; r.M = M; r.seq_len = T; r.row_len = w.lens2;
-      if (gemm_tn_forward(W.res, r, st)) return 1;
+      if (gemm_forward(W.res, r, st)) return 1;
     }
     GemmArgs s;        // output += skip ; the last layer's epilogue applies "* x_mask" to the finished sum
     s.x = w.wn_acts; s.ldx = Wh; s.y = w.wn_out; s.ldy = Wh; s.M = M;
     if (l > 0) { s.res = w.wn_out; s.ldr = Wh; }
     if (l == L - 1) { s.seq_len = T; s.row_len = w.lens2; }
-    if (gemm_tn_forward(W.skip, s, st)) return 1;
+    if (gemm_forward(W.skip, s, st)) return 1;
   }
   if (gemm(m.res_proj, w.xres, D, w.hmid, Wh, M, st, ACT_NONE, w.wn_out, Wh)) return 1;
   {
@@ -510,12 +517,12 @@ int S2MelModel::prepare_cond(const float* latent, const long long* codes, const 
   for (int n = 0; n < cfg.lr_num_convs; ++n) {
     GemmArgs g;
     g.x = cur; g.ldx = LC; g.y = other; g.ldy = LC; g.M = rowsT; g.taps = 3; g.seq_len = Tg; g.dil = 1; g.pad_left = 1; g.pad_mode = 0;
-    if (gemm_tn_forward(lr_conv[n], g, st)) return 1;
+    if (gemm_forward(lr_conv[n], g, st)) return 1;
     if (groupnorm1_mish(cur, other, lr_gn_g[n], lr_gn_b[n], w.tlen, B, Tg, LC, 1e-5f, w.stats, st)) return 1;
   }
   GemmArgs o;
   o.x = cur; o.ldx = LC; o.y = cond_out; o.ldy = LC; o.M = rowsT; o.seq_len = Tg; o.row_len = w.tlen;    // * mask
-  return gemm_tn_forward(lr_out, o, st);
+  return gemm_forward(lr_out, o, st);
 }
 
 }  // namespace idxtts

@@ -22,7 +22,7 @@ SYMBOLS = [
     "idxtts_linear_create", "idxtts_linear_fwd", "idxtts_linear_destroy", "idxtts_attention_fwd", "idxtts_layernorm_fwd",
     "idxtts_gpt_create", "idxtts_gpt_workspace_bytes", "idxtts_gpt_embed", "idxtts_gpt_generate", "idxtts_gpt_latent",
     "idxtts_s2mel_create", "idxtts_s2mel_cond_workspace_bytes", "idxtts_s2mel_prepare_cond",
-    "idxtts_s2mel_cfm_workspace_bytes", "idxtts_s2mel_cfm",
+    "idxtts_s2mel_cfm_workspace_bytes", "idxtts_s2mel_cfm", "idxtts_set_gemm_mode", "idxtts_get_gemm_mode",
 ]
 
 
@@ -79,7 +79,8 @@ def load() -> ctypes.CDLL:
                                        c_void_p, c_void_p]
     c_long = ctypes.c_long
     lib.idxtts_linear_create.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_void_p)]
-    lib.idxtts_linear_fwd.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]
+    lib.idxtts_linear_fwd.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    lib.idxtts_set_gemm_mode.argtypes = [c_int]
     lib.idxtts_linear_destroy.argtypes = [c_void_p]
     lib.idxtts_attention_fwd.argtypes = [c_void_p] * 4 + [c_long, c_int, c_long, c_int, c_long, c_int, c_int, c_int, c_int, c_int,
                                                           c_int, c_void_p, c_void_p, c_float, c_void_p]
@@ -163,3 +164,15 @@ def profile_read() -> dict:
             out[lib.idxtts_profile_kernel_name(i).decode()] = {
                 "ms": ms.value, "flops": fl.value, "bytes": by.value, "launches": n.value}
     return out
+
+
+GEMM_F32, GEMM_BF16X3 = 0, 1
+
+
+def set_gemm_mode(mode: int) -> None:
+    """0 = exact fp32 MFMA everywhere; 1 (library default) = split-bf16 for the GEMM-shaped passes with M >= 256."""
+    check(load().idxtts_set_gemm_mode(int(mode)))
+
+
+def get_gemm_mode() -> int:
+    return int(load().idxtts_get_gemm_mode())

@@ -16,7 +16,7 @@ from indextts_amd.config import GPTConfig
 pytestmark = pytest.mark.gpu
 
 
-def _linear(device, w, b, x, act=0, res=None, kn=False):
+def _linear(device, w, b, x, act=0, res=None, kn=False, bf16x3=0):
     lib = _lib.load()
     N, K = (w.shape[1], w.shape[0]) if kn else w.shape
     h = c_void_p()
@@ -27,7 +27,7 @@ def _linear(device, w, b, x, act=0, res=None, kn=False):
     No = N // 2 if act == 3 else N
     y = torch.empty(M, No, device=device)
     rd = None if res is None else res.to(device).contiguous()
-    _lib.check(lib.idxtts_linear_fwd(h, _lib.ptr(xd), xd.shape[1], _lib.ptr(y), No, _lib.ptr(rd), No, M, act, _lib.current_stream()))
+    _lib.check(lib.idxtts_linear_fwd(h, _lib.ptr(xd), xd.shape[1], _lib.ptr(y), No, _lib.ptr(rd), No, M, act, bf16x3, _lib.current_stream()))
     out = y.cpu()
     lib.idxtts_linear_destroy(h)
     return out
@@ -49,6 +49,22 @@ def test_gemm_tn_vs_torch(device, shape):
     gelu = 0.5 * pre * (1 + torch.tanh(math.sqrt(2 / math.pi) * (pre + 0.044715 * pre ** 3)))
     y2 = _linear(device, w.t().contiguous(), b, x, act=1, res=r, kn=True)
     assert (y2 - (gelu + r.double()).float()).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(256, 128, 32), (300, 1536, 512), (1000, 512, 864), (129, 80, 512), (640, 512, 1536), (513, 8194, 128)])
+def test_gemm_split_bf16_vs_torch(device, shape):
+    """Split-bf16 GEMM (3 bf16 MFMAs per product): relative error ~2^-16 per product, i.e. ~1e-5 of the row scale."""
+    M, N, K = shape
+    x = torch.from_numpy(synth.uniform(f"t/gemm16/x/{shape}", (M, K), 1.0))
+    w = torch.from_numpy(synth.fan_in_uniform(f"t/gemm16/w/{shape}", (N, K), K))
+    b = torch.from_numpy(synth.uniform(f"t/gemm16/b/{shape}", (N,), 0.2))
+    ref = (x.double() @ w.double().t() + b.double()).float()
+    y = _linear(device, w, b, x, bf16x3=1)
+    err = (y - ref).abs().max().item()
+    assert err <= 1e-4 * max(1.0, ref.abs().max().item()), err
+    assert (y - ref).abs().mean().item() <= 1e-5
+    # and it really is more accurate than plain bf16 would be (sanity: plain bf16 error would be ~4e-3)
+    assert err < 1e-3
 
 
 def test_gemm_swiglu_and_silu(device):
@@ -194,3 +210,29 @@ def test_eos_and_padding_invariance(device):
     solo, _ = uv.inference_speech(lat[3:4], text[3:4, :2], emo_vec=emo[3:4], max_generate_length=c.shape[1], repetition_penalty=10.0)
     n = min(solo.shape[1], c.shape[1])
     assert np.array_equal(solo.cpu().numpy()[0, :n], c[3, :n])
+
+
+def test_latent_pass_split_bf16_vs_oracle(device):
+    """A latent pass long enough (B*S >= 256 rows) for the split-bf16 GEMMs; greedy decode is unaffected (always fp32)."""
+    from indextts_amd import _lib
+    from indextts_amd.gpt import UnifiedVoice
+    from oracle import gpt as og
+    cfg = GPTConfig.tiny()
+    w = weights.synth_gpt_weights(cfg, tag="t/gpt/lat16")
+    uv = UnifiedVoice(w, cfg, device=device)
+    tw = {k: torch.from_numpy(v) for k, v in w.items()}
+    B, L, M = 3, 40, 100
+    lat = torch.from_numpy(synth.uniform("t/gpt/lat16/lat", (B, cfg.cond_latents, cfg.model_dim), 0.5))
+    emo = torch.from_numpy(synth.uniform("t/gpt/lat16/emo", (B, cfg.model_dim), 0.3))
+    text = torch.from_numpy(synth.integers("t/gpt/lat16/text", (B, L), 2, cfg.number_text_tokens))
+    codes = torch.from_numpy(synth.integers("t/gpt/lat16/codes", (B, M), 0, cfg.start_mel_token))
+    ref = og.latent_forward(tw, cfg, lat, text, codes, emo)
+    errs = {}
+    try:
+        for name, mode in (("f32", _lib.GEMM_F32), ("bf16x3", _lib.GEMM_BF16X3)):
+            _lib.set_gemm_mode(mode)
+            out = uv.forward(lat, text, torch.full((B,), L), codes, torch.full((B,), M), emo_vec=emo).cpu()
+            errs[name] = (out - ref).abs().max().item()
+    finally:
+        _lib.set_gemm_mode(_lib.GEMM_BF16X3)
+    assert errs["f32"] <= 1e-4 and errs["bf16x3"] <= 2e-3 and errs["bf16x3"] > 0

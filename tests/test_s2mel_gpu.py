@@ -116,3 +116,29 @@ def test_cfm_full_width_smoke(device):
     err = (out - ref).abs()
     assert err.max().item() <= 5e-4 * max(1.0, ref.abs().max().item()), err.max().item()
     assert err.mean().item() <= 1e-4
+
+
+def test_cfm_split_bf16_mode_vs_oracle(device, golden_dir):
+    """Sequences long enough (2B*T >= 256 rows) to take the split-bf16 GEMM path: mel error stays far inside the
+    north-star bound (L1 <= 1e-3), and the exact-fp32 mode is available and tighter."""
+    from indextts_amd import _lib
+    from oracle import s2mel as osm
+    g, cfg, w, sm = _tiny(golden_dir, device)
+    tw = {k: torch.from_numpy(v) for k, v in w.items()}
+    B, Tp, T = 1, 40, 170
+    z = torch.from_numpy(synth.uniform("t/s2mel/b16/z", (B, cfg.in_channels, T), 1.7))
+    mu = torch.from_numpy(synth.uniform("t/s2mel/b16/mu", (B, T, cfg.content_dim), 1.0))
+    prompt = torch.from_numpy(synth.uniform("t/s2mel/b16/prompt", (B, cfg.in_channels, Tp), 1.0))
+    st = torch.from_numpy(synth.uniform("t/s2mel/b16/style", (B, cfg.style_dim), 1.0))
+    ref = osm.cfm_inference(tw, cfg, mu, torch.LongTensor([T]), prompt, st, z, 3, 0.7)
+    res = {}
+    try:
+        for name, mode in (("f32", _lib.GEMM_F32), ("bf16x3", _lib.GEMM_BF16X3)):
+            _lib.set_gemm_mode(mode)
+            out = sm.cfm_inference(mu, torch.LongTensor([T]), prompt, st, None, 3, inference_cfg_rate=0.7, z=z).cpu()
+            res[name] = (out - ref).abs()
+    finally:
+        _lib.set_gemm_mode(_lib.GEMM_BF16X3)
+    assert res["f32"].max().item() <= 3e-4 and res["f32"].mean().item() <= 2e-5
+    assert res["bf16x3"].mean().item() <= 1e-4 and res["bf16x3"].max().item() <= 3e-3      # bound: mel L1 <= 1e-3
+    assert res["bf16x3"].mean().item() > 0
