@@ -150,9 +150,9 @@ int decode_attn_forward(const DecodeAttnArgs& a, hipStream_t stream) {
 }
 
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sample_greedy_kernel(const SampleArgs p) {
-  __shared__ float rv[4];
-  __shared__ int ri[4];
+__global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs p) {
+  __shared__ float rv[16];
+  __shared__ int ri[16];
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int V = p.V;
   float best = -INFINITY;
@@ -160,23 +160,23 @@ __global__ __launch_bounds__(256) void sample_greedy_kernel(const SampleArgs p) 
   const unsigned char* seen = p.seen + (size_t)b * V;
   const size_t sst = (size_t)p.part_rows * V;
   const float* prow = p.part + (size_t)b * V;
-  for (int v0 = tid; v0 < V; v0 += 1024) {       // 4 vocabulary entries per trip, all their slab loads in flight together
+  for (int v0 = tid; v0 < V; v0 += 4096) {       // 4 vocabulary entries per trip, all their slab loads in flight together
     float l4[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int v = v0 + 256 * u;
+      const int v = v0 + 1024 * u;
       l4[u] = (v < V && p.bias) ? p.bias[v] : 0.0f;
     }
     for (int s = 0; s < p.parts; ++s) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int v = v0 + 256 * u;
+        const int v = v0 + 1024 * u;
         if (v < V) l4[u] += prow[(size_t)s * sst + v];
       }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int v = v0 + 256 * u;
+      const int v = v0 + 1024 * u;
       if (v >= V) continue;
       float l = l4[u];
       if (p.logits_out) p.logits_out[(size_t)b * V + v] = l;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void sample_greedy_kernel(const SampleArgs p) 
   if (lane == 0) { rv[wave] = best; ri[wave] = bidx; }
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < 16; ++w)
       if (rv[w] > best || (rv[w] == best && ri[w] < bidx)) { best = rv[w]; bidx = ri[w]; }
     int tok = p.finished[b] ? p.stop_token : bidx;      // finished rows emit pad (= eos = stop token)
     p.codes[(size_t)b * p.codes_ld + p.st->step] = tok;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void sample_greedy_kernel(const SampleArgs p) 
 int sample_greedy_forward(const SampleArgs& a, hipStream_t stream) {
   IDX_CHECK(a.part && a.seen && a.finished && a.codes && a.cur_tok && a.st, "null pointer");
   ProfScope prof(PROF_SAMPLE, stream, 0.0, 4.0 * a.B * (double)a.V * (a.parts + 1));
-  hipLaunchKernelGGL(sample_greedy_kernel, dim3(a.B), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(sample_greedy_kernel, dim3(a.B), dim3(1024), 0, stream, a);
   IDX_LAUNCH_CHECK();
   return 0;
 }

@@ -18,12 +18,15 @@
 // ds_read_b128 fragment read conflict-free (rows r and r+4 of an unpadded 64-byte row would share banks).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "gemm_common.h"
 #include "prof.h"
 
 namespace idxtts {
+
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -185,6 +188,167 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmKP p) {
   gemm_epilogue(p, acc, bm, bn, wm, wn, h, j);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Large-M variant: 256 x (64*TN) workgroup tile, 512 threads = 8 waves as 4 (M) x 2 (N), wave tile 64 x (32*TN).
+// The 128x128 kernel above needs 48 B/clk/CU of operand traffic at the bf16 MFMA rate (measured: a CU sustains ~13,
+// L2 hit rate 66 %); doubling the rows a weight tile is applied to halves the weight traffic per flop and doubles the
+// MFMA work per barrier (one workgroup per CU, two waves per SIMD).
+template <int TN>
+__global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(const GemmKP p) {
+  constexpr int BN = 64 * TN;                 // columns per workgroup
+  constexpr int NB128 = BN / 128 > 0 ? BN / 128 : 1;   // packed 128-column weight tiles per k-step
+  constexpr int A_HALF = 256 * BROW;          // elements of one [256][40] activation image
+  constexpr int B_HALF = TILE_HALF;           // [128][40] per packed weight tile (hi or lo)
+  constexpr int A_STAGE = 2 * A_HALF, B_STAGE = NB128 * 2 * B_HALF;
+  constexpr int NWL = (NB128 * 1280 + 511) / 512;      // 16-byte weight loads per thread per k-step
+  static_assert(BN == 128 || BN == 256, "tile");
+  extern __shared__ __attribute__((aligned(16))) __bf16 sm16[];
+  __bf16* As = sm16;                          // [2][hl][256][40]
+  __bf16* Bs = sm16 + 2 * A_STAGE;            // [2][NB128][hl][128][40]
+
+  const int L = blockIdx.x, xcd = L & 7, q = L >> 3;
+  int bn, bm;
+  if (p.n_fast) { const int bml = q / p.nblocks; bn = q - bml * p.nblocks; bm = bml * 8 + xcd; }
+  else { bn = q / p.mt8; bm = (q - bn * p.mt8) * 8 + xcd; }
+  if (bm >= p.mtiles) return;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int h = lane >> 5, j = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ksteps = (p.K + 31) >> 5;
+
+  f32x4 xr[4];
+  f32x4 wr[NWL];
+  int seq_base[4], seq_t[4], seq_n[4];
+  if (p.taps > 1) {
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const int m = bm * 256 + ((tid + 512 * l) >> 3);
+      const int sb = m / p.seq_len;
+      seq_base[l] = sb * p.seq_len;
+      seq_t[l] = m - sb * p.seq_len;
+      seq_n[l] = (p.row_len && m < p.M) ? min(p.row_len[sb], p.seq_len) : p.seq_len;
+    }
+  }
+  const int n128 = cdiv_dev(p.N, 128);
+  auto load_tiles = [&](int kstep) {
+    int tap = 0, kk0 = kstep * 32;
+    if (p.taps > 1) { tap = kk0 / p.kc; kk0 -= tap * p.kc; }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const int idx = tid + 512 * l;
+      const int row = idx >> 3, q8 = idx & 7;
+      const int m = bm * 256 + row, k = kstep * 32 + q8 * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (p.taps > 1) {
+        int t = seq_t[l] + tap * p.dil - p.pad_left;
+        if (p.pad_mode == 1) { t = t < 0 ? -t : t; t = t >= seq_n[l] ? 2 * (seq_n[l] - 1) - t : t; }
+        if (m < p.M && k < p.K && t >= 0 && t < seq_n[l])
+          v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(seq_base[l] + t) * p.ldx + kk0 + q8 * 4);
+      } else if (m < p.M && k < p.K) {
+        v = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.ldx + k);
+      }
+      xr[l] = v;
+    }
+#pragma unroll
+    for (int l = 0; l < NWL; ++l) {
+      const int idx = tid + 512 * l;                 // 16-byte unit inside this k-step's weight tiles
+      const int sub = idx / 1280, off = idx - sub * 1280;
+      const int nb = bn * NB128 + sub;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < NB128 * 1280 && nb < n128)
+        v = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.wp) + ((size_t)nb * ksteps + kstep) * WTILE_BYTES)[off];
+      wr[l] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    __bf16* a_hi = As + buf * A_STAGE;
+    __bf16* a_lo = a_hi + A_HALF;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const int idx = tid + 512 * l;
+      const int row = idx >> 3, q8 = idx & 7;
+      const bf16x4 hi = __builtin_convertvector(xr[l], bf16x4);
+      const f32x4 back = __builtin_convertvector(hi, f32x4);
+      const bf16x4 lo = __builtin_convertvector(xr[l] - back, bf16x4);
+      *reinterpret_cast<bf16x4*>(a_hi + row * BROW + q8 * 4) = hi;
+      *reinterpret_cast<bf16x4*>(a_lo + row * BROW + q8 * 4) = lo;
+    }
+    f32x4* wdst = reinterpret_cast<f32x4*>(Bs + buf * B_STAGE);
+#pragma unroll
+    for (int l = 0; l < NWL; ++l) {
+      const int idx = tid + 512 * l;
+      if (idx < NB128 * 1280) wdst[idx] = wr[l];
+    }
+  };
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const bool has_next = ks + 1 < ksteps;
+    if (has_next) load_tiles(ks + 1);
+    const __bf16* a_hi = As + (ks & 1) * A_STAGE;
+    const __bf16* b_st = Bs + (ks & 1) * B_STAGE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 ah[2], al[2], bh[TN], bl[TN];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int ar = (wm * 64 + t * 32 + j) * BROW + s * 16 + h * 8;
+        ah[t] = *reinterpret_cast<const bf16x8*>(a_hi + ar);
+        al[t] = *reinterpret_cast<const bf16x8*>(a_hi + A_HALF + ar);
+      }
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        const int col = wn * 32 * TN + t * 32 + j;                 // column inside the workgroup tile
+        const __bf16* bt = b_st + (col >> 7) * 2 * B_HALF + (col & 127) * BROW + s * 16 + h * 8;
+        bh[t] = *reinterpret_cast<const bf16x8*>(bt);
+        bl[t] = *reinterpret_cast<const bf16x8*>(bt + B_HALF);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    if (has_next) store_tiles((ks + 1) & 1);
+    __syncthreads();
+  }
+  gemm_epilogue_t<2, TN>(p, acc, bm * 256 + wm * 64, bn * BN + wn * 32 * TN, h, j);
+}
+
+template <int TN>
+static int launch_big(GemmKP p, const LinearWeights& w, const GemmArgs& a, hipStream_t stream, double flops, double bytes) {
+  constexpr int BN = 64 * TN, NB128 = BN / 128;
+  p.mtiles = cdiv(a.M, 256);
+  p.mt8 = cdiv(p.mtiles, 8);
+  p.nblocks = cdiv(w.N, BN);
+  const int64_t grid = (int64_t)8 * p.nblocks * p.mt8;
+  IDX_CHECK(grid < (1ll << 31), "grid size");
+  constexpr size_t lds = (size_t)(2 * 2 * 256 * BROW + 2 * NB128 * 2 * TILE_HALF) * sizeof(__bf16);
+  static bool attr_set = false;
+  if (!attr_set) {
+    IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  ProfScope prof(TN == 2 ? PROF_GEMM_BF16X3_256x128 : PROF_GEMM_BF16X3_256x256, stream, flops, bytes);
+  hipLaunchKernelGGL(gemm_bf16x3_big_kernel<TN>, dim3((unsigned)grid), dim3(512), lds, stream, p);
+  IDX_LAUNCH_CHECK();
+  return 0;
+}
+
 int gemm_bf16x3_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t stream) {
   IDX_CHECK(w.wp16 && a.x && a.y, "null pointer (split-bf16 weights not packed?)");
   if (a.M == 0) return 0;
@@ -213,6 +377,12 @@ int gemm_bf16x3_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t s
   IDX_CHECK(grid < (1ll << 31), "grid size");
   const double flops = 2.0 * a.M * (double)w.N * w.K;
   const double bytes = 4.0 * ((double)a.M * w.K + (double)w.N * w.K + (double)a.M * w.N * (a.res ? 2.0 : 1.0));
+  static int tile_sel = getenv("IDXTTS_GEMM_TILE") ? atoi(getenv("IDXTTS_GEMM_TILE")) : 2;   // 0: 128x128, 1: 256x128, 2: 256x256
+  if (tile_sel >= 1 && a.M >= 4096) {
+    const bool paired = a.act == ACT_SWIGLU || a.act == ACT_GATE;
+    if (tile_sel == 2 && w.N >= 256 && !paired) return launch_big<4>(p, w, a, stream, flops, bytes);
+    return launch_big<2>(p, w, a, stream, flops, bytes);
+  }
   constexpr size_t lds = (size_t)(2 * 2 * 2 * TILE_HALF) * sizeof(__bf16);
   static bool attr_set = false;
   if (!attr_set) {

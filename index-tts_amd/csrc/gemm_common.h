@@ -33,45 +33,51 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 }
 
 
-// acc[mt][nt][r]: row = bm*128 + wm*64 + mt*32 + (r&3) + 8*(r>>2) + 4*h, col = bn*128 + wn*64 + nt*32 + j
-__device__ __forceinline__ void gemm_epilogue(const GemmKP& p, f32x16 (&acc)[2][2], int bm, int bn, int wm, int wn, int h, int j) {
-  // ---- epilogue ----
+// Wave-tile epilogue in the 32x32 MFMA C/D layout: acc[mt][nt][r] is element
+//   row = row0 + mt*32 + (r&3) + 8*(r>>2) + 4*h,  packed column = col0 + nt*32 + j
+// (row0/col0 = first row / first packed column of the wave's tile).  Bias, activation or paired gate
+// (tiles (2q, 2q+1) = [gate | linear]), residual, row mask, store.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_t(const GemmKP& p, f32x16 (&acc)[TM][TN], int row0, int col0, int h, int j) {
   auto row_masked = [&](int m) -> bool {
     if (!p.row_len) return false;
     const int sb = m / p.seq_len;
     return (m - sb * p.seq_len) >= p.row_len[sb];
   };
   if (p.act == ACT_SWIGLU || p.act == ACT_GATE) {
-    // packed rows alternate [32 of w1 | 32 of w3]: acc[.][0] is the gate, acc[.][1] the linear branch
-    const int n0 = bn * 128 + wn * 64 + j;            // packed column of the gate
-    const int no = bn * 64 + wn * 32 + j;             // output column
-    const bool ok = (bn * 128 + wn * 64) < p.N;       // N % 64 == 0: a wave's 64 packed columns are all in or all out
-    const float b0 = (p.bias && ok) ? p.bias[n0] : 0.0f, b1 = (p.bias && ok) ? p.bias[n0 + 32] : 0.0f;
+    static_assert(TN % 2 == 0, "paired activations need an even number of column tiles per wave");
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int q = 0; q < TN / 2; ++q) {
+      const int n0 = col0 + q * 64 + j;               // packed column of the gate
+      const int no = ((col0 + q * 64) >> 1) + j;      // output column
+      const bool ok = (col0 + q * 64) < p.N;          // N % 64 == 0: 64 packed columns are all in or all out
+      const float b0 = (p.bias && ok) ? p.bias[n0] : 0.0f, b1 = (p.bias && ok) ? p.bias[n0 + 32] : 0.0f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = bm * 128 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= p.M || !ok) continue;
-        const float gte = acc[mt][0][r] + b0, lin = acc[mt][1][r] + b1;
-        float v = p.act == ACT_SWIGLU ? (gte / (1.0f + expf(-gte))) * lin : tanhf(gte) * (1.0f / (1.0f + expf(-lin)));
-        v *= p.out_scale;
-        if (p.res) v += p.res[(size_t)m * p.ldr + no];
-        if (row_masked(m)) v = 0.0f;
-        p.y[(size_t)m * p.ldy + no] = v;
-      }
+      for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = row0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m >= p.M || !ok) continue;
+          const float gte = acc[mt][2 * q][r] + b0, lin = acc[mt][2 * q + 1][r] + b1;
+          float v = p.act == ACT_SWIGLU ? (gte / (1.0f + expf(-gte))) * lin : tanhf(gte) * (1.0f / (1.0f + expf(-lin)));
+          v *= p.out_scale;
+          if (p.res) v += p.res[(size_t)m * p.ldr + no];
+          if (row_masked(m)) v = 0.0f;
+          p.y[(size_t)m * p.ldy + no] = v;
+        }
+    }
     return;
   }
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int n = bn * 128 + wn * 64 + nt * 32 + j;
+  for (int nt = 0; nt < TN; ++nt) {
+    const int n = col0 + nt * 32 + j;
     if (n >= p.N) continue;
     const float bias = p.bias ? p.bias[n] : 0.0f;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = bm * 128 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int m = row0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m >= p.M) continue;
         float v = act_apply(acc[mt][nt][r] + bias, p.act) * p.out_scale;
         if (p.res) v += p.res[(size_t)m * p.ldr + n];
@@ -79,6 +85,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmKP& p, f32x16 (&acc)[2][
         p.y[(size_t)m * p.ldy + n] = v;
       }
   }
+}
+
+// 128x128 workgroup tile, 2x2 waves of 64x64
+__device__ __forceinline__ void gemm_epilogue(const GemmKP& p, f32x16 (&acc)[2][2], int bm, int bn, int wm, int wn, int h, int j) {
+  gemm_epilogue_t<2, 2>(p, acc, bm * 128 + wm * 64, bn * 128 + wn * 64, h, j);
 }
 
 }  // namespace idxtts

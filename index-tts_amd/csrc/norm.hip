@@ -62,31 +62,23 @@ __global__ __launch_bounds__(256) void rows_norm_kernel(const RowsNormArgs p) {
     v[i] = a;
   }
   if (p.num_partials > 0) {
-    // split-K slabs: every trip issues 4 x NPER independent loads before the adds (the decode step has only
-    // `rows` workgroups in flight, so memory-level parallelism has to come from inside the thread)
+    // split-K slabs: the decode step has only `rows` workgroups in flight, so memory-level parallelism has to come from
+    // inside the thread: groups of 8 slabs x NPER elements are issued back to back before any add (fixed summation order)
     const float* pbase = p.partials + (size_t)m * p.ld_partial;
     const size_t sstride = (size_t)p.partial_rows * p.ld_partial;
-    int s = 0;
-    for (; s + 4 <= p.num_partials; s += 4) {
-      float t0[NPER], t1[NPER], t2[NPER], t3[NPER];
+    for (int s0 = 0; s0 < p.num_partials; s0 += 8) {
+      float t[8][NPER];
 #pragma unroll
-      for (int i = 0; i < nper; ++i) {
-        const int e = tid + (i << 8);
-        const bool ok = e < d;
-        t0[i] = ok ? pbase[(size_t)(s + 0) * sstride + e] : 0.f;
-        t1[i] = ok ? pbase[(size_t)(s + 1) * sstride + e] : 0.f;
-        t2[i] = ok ? pbase[(size_t)(s + 2) * sstride + e] : 0.f;
-        t3[i] = ok ? pbase[(size_t)(s + 3) * sstride + e] : 0.f;
-      }
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
-      for (int i = 0; i < nper; ++i) v[i] = (((v[i] + t0[i]) + t1[i]) + t2[i]) + t3[i];
-    }
-    for (; s < p.num_partials; ++s) {
+        for (int i = 0; i < nper; ++i) {
+          const int e = tid + (i << 8);
+          t[u][i] = (s0 + u < p.num_partials && e < d) ? pbase[(size_t)(s0 + u) * sstride + e] : 0.f;
+        }
 #pragma unroll
-      for (int i = 0; i < nper; ++i) {
-        const int e = tid + (i << 8);
-        if (e < d) v[i] += pbase[(size_t)s * sstride + e];
-      }
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int i = 0; i < nper; ++i) v[i] += t[u][i];
     }
   }
   if (p.x_out) {

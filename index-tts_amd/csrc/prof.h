@@ -8,7 +8,7 @@ namespace idxtts {
 enum ProfCat {
   PROF_CONV_128x128 = 0, PROF_CONV_96x256, PROF_CONV_64x256, PROF_CONV_32x512,
   PROF_AA_ACT, PROF_CONV_POST,
-  PROF_GEMM_TN, PROF_GEMM_BF16X3, PROF_FLASH_ATTN, PROF_ROWS_NORM, PROF_GEMV16, PROF_DECODE_ATTN, PROF_SAMPLE, PROF_EMBED, PROF_ELTWISE,
+  PROF_GEMM_TN, PROF_GEMM_BF16X3, PROF_GEMM_BF16X3_256x128, PROF_GEMM_BF16X3_256x256, PROF_FLASH_ATTN, PROF_ROWS_NORM, PROF_GEMV16, PROF_DECODE_ATTN, PROF_SAMPLE, PROF_EMBED, PROF_ELTWISE,
   PROF_NCAT
 };
 

@@ -9,7 +9,7 @@ namespace idxtts {
 
 static const char* kNames[PROF_NCAT] = {
     "conv1d_mfma_128x128", "conv1d_mfma_96x256", "conv1d_mfma_64x256", "conv1d_mfma_32x512", "aa_act", "conv_post",
-    "gemm_tn_128x128", "gemm_bf16x3_128x128", "flash_attn_f32", "rows_norm", "gemv16_mfma", "decode_attn", "sample_greedy", "embed_rows", "eltwise"};
+    "gemm_tn_128x128", "gemm_bf16x3_128x128", "gemm_bf16x3_256x128", "gemm_bf16x3_256x256", "flash_attn_f32", "rows_norm", "gemv16_mfma", "decode_attn", "sample_greedy", "embed_rows", "eltwise"};
 
 struct Rec { hipEvent_t a, b; int cat; };
 static std::mutex g_mu;
