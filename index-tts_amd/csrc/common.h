@@ -20,6 +20,12 @@ int fail(const char* file, int line, const std::string& msg);
     IDX_FAIL(std::string(#expr " -> ") + hipGetErrorString(e__)); } while (0)
 #define IDX_LAUNCH_CHECK() IDX_HIP(hipGetLastError())
 
+// Decode-step activations are kept as MFMA A-fragment images (v_mfma_f32_16x16x4_f32): [rows/16][K/16][64 lanes][4],
+// lane = (k % 16) / 4 * 16 + row % 16, component = k % 4 -- the fragment of a 16-k chunk is one contiguous KiB.
+__host__ __device__ static inline size_t frag_index(int row, int k, int kc16) {
+  return ((((size_t)(row >> 4) * kc16 + (k >> 4)) * 64 + ((k & 15) >> 2) * 16 + (row & 15)) << 2) + (k & 3);
+}
+static inline size_t frag_image_floats(int rows, int K) { return (size_t)((rows + 15) / 16) * ((K + 15) / 16) * 256; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

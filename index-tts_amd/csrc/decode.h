@@ -14,7 +14,7 @@ struct DecodeAttnArgs {
   const float* qkv_part = nullptr; int parts = 0; int part_rows = 0;   // [parts][part_rows][3d] c_attn split-K slab
   const float* qkv_bias = nullptr;                                      // [3d]
   float* kcache = nullptr; float* vcache = nullptr;                     // this layer: [B][H][16][Smax][4] / [B][H][Smax][64]
-  float* out = nullptr;                                                 // [B][d]
+  float* out = nullptr;                                                 // [B][d] as A-fragment images (frag_index)
   const int* kstart = nullptr;                                          // [B] first valid key (left pad), or null
   const DecodeState* st = nullptr;
   int B = 0, H = 0, Smax = 0, d = 0;

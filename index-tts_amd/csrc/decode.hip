@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
     const int col = which * d + h * 64 + dd;
     const float* row = p.qkv_part + (size_t)b * 3 * d + col;
     const size_t sst = (size_t)p.part_rows * 3 * d;
-    float acc = p.qkv_bias[col];
+    float acc = p.qkv_bias ? p.qkv_bias[col] : 0.0f;
     int s = 0;
     for (; s + 4 <= p.parts; s += 4) {
       const float t0 = row[(size_t)(s + 0) * sst], t1 = row[(size_t)(s + 1) * sst], t2 = row[(size_t)(s + 2) * sst], t3 = row[(size_t)(s + 3) * sst];
@@ -128,12 +128,12 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
     float o = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) o += outp[g * 64 + tid];
-    p.out[(size_t)b * d + h * 64 + tid] = l > 0.f ? o / l : 0.f;
+    p.out[frag_index(b, h * 64 + tid, d >> 4)] = l > 0.f ? o / l : 0.f;     // A-fragment image for the c_proj GEMV
   }
 }
 
 int decode_attn_forward(const DecodeAttnArgs& a, hipStream_t stream) {
-  IDX_CHECK(a.qkv_part && a.qkv_bias && a.kcache && a.vcache && a.out && a.st, "null pointer");
+  IDX_CHECK(a.qkv_part && a.kcache && a.vcache && a.out && a.st, "null pointer");
   IDX_CHECK(a.d == a.H * 64, "head_dim must be 64");
   const size_t lds = (size_t)(256 + 1024 + a.Smax) * sizeof(float);
   IDX_CHECK(lds <= 160 * 1024, "Smax too large for the LDS score buffer");
@@ -266,12 +266,12 @@ int gather_sum_rows(const GatherArgs& a, int rows, hipStream_t stream) {
   return 0;
 }
 
-// decode-step embedding: x[b] = mel_emb[cur_tok[b]] + mel_pos[st->mel_pos]
+// decode-step embedding: x[b] = mel_emb[cur_tok[b]] + mel_pos[st->mel_pos], written as A-fragment images (common.h)
 __global__ __launch_bounds__(256) void embed_step_kernel(float* x, int d, const float* mel_emb, const float* mel_pos,
                                                          const int* cur_tok, const DecodeState* st) {
   const int b = blockIdx.x;
   const int tok = cur_tok[b], mp = st->mel_pos;
-  for (int e = threadIdx.x; e < d; e += 256) x[(size_t)b * d + e] = mel_emb[(size_t)tok * d + e] + mel_pos[(size_t)mp * d + e];
+  for (int e = threadIdx.x; e < d; e += 256) x[frag_index(b, e, d >> 4)] = mel_emb[(size_t)tok * d + e] + mel_pos[(size_t)mp * d + e];
 }
 
 int embed_step(float* x, int B, int d, const float* mel_emb, const float* mel_pos, const int* cur_tok, const DecodeState* st,

@@ -1,0 +1,292 @@
+// Decode-step skinny GEMM: Y[rows <= 64][N] = epi(LN?(X)[rows][K] . W[K][N]), one HBM pass over the weights, no split-K
+// slabs, no LayerNorm launch, no prologue.  Replaces, per generated token, the Conv1D projections of every GPT-2 block
+// (transformers_gpt2.py:304-355, 578-592), the LayerNorms in front of c_attn / c_fc (615-674) and the residual adds
+// behind c_proj / mlp.c_proj: 5 launches per layer (c_attn, attention, c_proj, c_fc, mlp.c_proj).
+//
+// What bounds it (tools/stream_probe.hip, tools/gemv_probe.hip on MI355X): a cold 26 MB weight stream alone takes 5.9 us
+// (4.5 TB/s) when >= ~256 waves x 5 KiB are in flight; everything else in the kernel is a chain of dependent
+// L2 / LDS round trips (~1-2 us each), so the kernel is built to have as few of those as possible:
+//   * activations live in HBM as MFMA A-fragment images ([rows/16][K/16][64 lanes][4], frag_index() in common.h): the
+//     activation fragment of a 16-k chunk is ONE contiguous 1 KiB load (8 full cache lines), exactly like the weight
+//     fragment (packed [N/16][K/16][64][4] for v_mfma_f32_16x16x4_f32), and both are issued together;
+//   * a wave owns a K-slice for NTW adjacent column tiles, so one activation fragment feeds NTW weight fragments
+//     (L2->L1 activation traffic = weight traffic / NTW);
+//   * LayerNorm is folded algebraically: with W' = diag(g) W, u = colsum(W'), c = b.W + bias (precomputed at load),
+//         LN(x) . W + bias = rstd * (x . W' - mean * u) + c
+//     so the matrix product runs on the RAW residual stream while the row statistics are accumulated from the very
+//     fragments the MFMAs consume (shifted sums per wave, Chan's pairwise update across the K-slices in a fixed order:
+//     as accurate as the two-pass form, bitwise reproducible);
+//   * the K-slices of the 16 waves of a workgroup are reduced through LDS in a fixed order; bias / colsum / residual
+//     operands of the epilogue are fetched at kernel entry.
+#include <algorithm>
+#include <cstdlib>
+
+#include "gemv16.h"
+#include "prof.h"
+
+namespace idxtts {
+
+// ---- host-side packing: B-fragment order of v_mfma_f32_16x16x4_f32, [N/16][K/16][lane][4], k = 4*(lane>>4)+s, n = lane&15 ----
+void pack_gemv16_kn(float* dst, const float* w_kn, int K, int N) {
+  const int NT = cdiv(N, 16), KC = cdiv(K, 16);
+  for (int nt = 0; nt < NT; ++nt)
+    for (int c = 0; c < KC; ++c) {
+      float* sub = dst + ((size_t)nt * KC + c) * 256;
+      for (int lane = 0; lane < 64; ++lane)
+        for (int s = 0; s < 4; ++s) {
+          const int k = c * 16 + 4 * (lane >> 4) + s, n = nt * 16 + (lane & 15);
+          sub[lane * 4 + s] = (k < K && n < N) ? w_kn[(size_t)k * N + n] : 0.0f;
+        }
+    }
+}
+
+void pack_gemv16_nk(float* dst, const float* w_nk, int N, int K) {
+  const int NT = cdiv(N, 16), KC = cdiv(K, 16);
+  for (int nt = 0; nt < NT; ++nt)
+    for (int c = 0; c < KC; ++c) {
+      float* sub = dst + ((size_t)nt * KC + c) * 256;
+      for (int lane = 0; lane < 64; ++lane)
+        for (int s = 0; s < 4; ++s) {
+          const int k = c * 16 + 4 * (lane >> 4) + s, n = nt * 16 + (lane & 15);
+          sub[lane * 4 + s] = (k < K && n < N) ? w_nk[(size_t)n * K + k] : 0.0f;
+        }
+    }
+}
+
+struct GemvFXP {
+  const float* xf;          // A-fragment images [MT][kc16][64][4]
+  const float* wp;          // packed weights [ntiles][kc16][64][4]
+  const float* bias;        // [N] or null (LN-folded layers: c = b.W + bias)
+  const float* colsum;      // [N] LN-folded layers: u = colsum(diag(g) W); null = plain GEMV
+  float ln_eps;
+  const float* res;         // residual, same layout as y, may alias y
+  float* y; int y_frag; int ldy;   // y_frag: fragment images with kc16 = N/16 (N % 16 == 0), else row-major [rows][ldy]
+  int rows, N, K, kc16, ntiles, kw, cps, act;
+  int dbg;
+};
+
+__device__ __forceinline__ float gelu_new_fx(float v) {
+  const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+  return 0.5f * v * (1.0f + tanhf(u));
+}
+
+// UN = chunks per register batch (two batches live: the next one is in flight while the current one is multiplied)
+template <int MT, int NTW>
+struct FXCfg { static constexpr int UN = (MT + NTW == 2) ? 5 : (NTW == 2 ? 3 : (MT == 2 ? 2 : 1)); };
+
+template <int MT, int NTW>
+__global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
+  constexpr int UN = FXCfg<MT, NTW>::UN;
+  constexpr int NACC = MT * NTW;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* redbuf = sm;                               // [kw][NACC][256]
+  float* wstat = sm + p.kw * NACC * 256;            // [kw][MT*16][2]  per K-slice: mean, M2 (count is known)
+  float* rstat = wstat + p.kw * MT * 32;            // [MT*16][2]      mean, rstd
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nt0 = blockIdx.x * NTW;
+  const int c0 = wave * p.cps;
+  const int nch = max(0, min(p.cps, p.kc16 - c0));
+  const bool ln = p.colsum != nullptr;
+
+  // ---- epilogue operands of this thread's output element, fetched up front ----
+  // element e = tid (< NACC*256): r = e & 3, ln16 = (e >> 2) & 63, t = e >> 8 -> (mt, ntw) = (t / NTW, t % NTW)
+  const int e_r = tid & 3, e_ln = (tid >> 2) & 63, e_t = tid >> 8;
+  const int e_mt = e_t / NTW, e_ntw = e_t - e_mt * NTW;
+  const int e_row = e_mt * 16 + (e_ln >> 4) * 4 + e_r, e_col = (nt0 + e_ntw) * 16 + (e_ln & 15);
+  const bool e_ok = e_t < NACC && e_row < p.rows && e_col < p.N;
+  size_t e_addr = 0;
+  float e_bias = 0.f, e_u = 0.f, e_res = 0.f;
+  if (e_ok) {
+    e_addr = p.y_frag ? frag_index(e_row, e_col, p.N >> 4) : (size_t)e_row * p.ldy + e_col;
+    if (p.bias) e_bias = p.bias[e_col];
+    if (ln) e_u = p.colsum[e_col];
+    if (p.res) e_res = p.res[e_addr];
+  }
+
+  // ---- K loop ----
+  f32x4 acc[MT][NTW];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* wbase[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) wbase[j] = p.wp + ((size_t)min(nt0 + j, p.ntiles - 1) * p.kc16 + c0) * 256 + lane * 4;
+  const float* xbase = p.xf + (size_t)c0 * 256 + lane * 4;
+  const size_t ximg = (size_t)p.kc16 * 256;
+
+  f32x4 wq[2][UN][NTW], xq[2][UN][MT];
+  auto load_batch = [&](int buf, int cb) {
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const bool ok = cb + u < nch;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+        wq[buf][u][j] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wbase[j] + (size_t)(cb + u) * 256)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        xq[buf][u][mt] = (ok && !(p.dbg & 1)) ? *reinterpret_cast<const f32x4*>(xbase + mt * ximg + (size_t)(cb + u) * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  // shifted row sums for the folded LayerNorm: this lane holds row (lane & 15) of every fragment
+  float shift[MT], s1[MT], s2[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) shift[mt] = s1[mt] = s2[mt] = 0.f;
+
+  load_batch(0, 0);
+  if (ln) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) shift[mt] = __shfl(xq[0][0][mt][0], lane & 15);   // a sample of the row as the shift
+  }
+  auto consume = [&](int buf, int cb) {
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (ln && cb + u < nch) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const float dlt = xq[buf][u][mt][s] - shift[mt];
+            s1[mt] += dlt;
+            s2[mt] += dlt * dlt;
+          }
+      }
+      if (p.dbg & 2) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) acc[mt][j] += xq[buf][u][mt] * wq[buf][u][j];
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+              acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[buf][u][mt][s], wq[buf][u][j][s], acc[mt][j], 0, 0, 0);
+      }
+    }
+  };
+  for (int cb = 0; cb < nch; cb += 2 * UN) {
+    if (cb + UN < nch) load_batch(1, cb + UN);
+    consume(0, cb);
+    if (cb + UN < nch) {
+      if (cb + 2 * UN < nch) load_batch(0, cb + 2 * UN);
+      consume(1, cb + UN);
+    }
+  }
+
+  if (p.dbg & 4) {
+    if (acc[0][0][0] == 123.456f) p.y[tid] = acc[0][0][1];
+    return;
+  }
+
+  // ---- per-slice partial results to LDS (waves beyond kw exist only as epilogue threads) ----
+  const bool kwave = wave < p.kw;
+  if (kwave)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) *reinterpret_cast<f32x4*>(&redbuf[((wave * NACC + mt * NTW + j) * 64 + lane) * 4]) = acc[mt][j];
+  if (ln && kwave) {
+    // the four lane groups (lane >> 4) hold disjoint k of the same row: fold them, then slice mean / M2 about the mean
+    const float cnt = 16.0f * nch;    // K-slice elements per row (padded chunks excluded: K % 16 == 0 for folded layers)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float a = s1[mt], b = s2[mt];
+      a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+      a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+      if (lane < 16) {
+        const float mean_w = nch > 0 ? shift[mt] + a / cnt : 0.f;
+        const float m2_w = nch > 0 ? b - a * a / cnt : 0.f;
+        wstat[(wave * MT * 16 + mt * 16 + lane) * 2 + 0] = mean_w;
+        wstat[(wave * MT * 16 + mt * 16 + lane) * 2 + 1] = m2_w;
+      }
+    }
+  }
+  __syncthreads();
+  if (ln) {
+    if (tid < MT * 16) {     // Chan / Welford pairwise update over the K-slices, fixed order
+      float n = 0.f, mean = 0.f, m2 = 0.f;
+      for (int w = 0; w < p.kw; ++w) {
+        const float nw = 16.0f * max(0, min(p.cps, p.kc16 - w * p.cps));
+        if (nw == 0.f) continue;
+        const float mw = wstat[(w * MT * 16 + tid) * 2], qw = wstat[(w * MT * 16 + tid) * 2 + 1];
+        const float dlt = mw - mean, nn = n + nw;
+        mean += dlt * (nw / nn);
+        m2 += qw + dlt * dlt * (n * nw / nn);
+        n = nn;
+      }
+      rstat[tid * 2] = mean;
+      rstat[tid * 2 + 1] = rsqrtf(m2 / n + p.ln_eps);
+    }
+    __syncthreads();
+  }
+
+  // ---- fixed-order reduction over the K-slices and the epilogue: one output element per thread ----
+  if (e_t < NACC) {
+    float v = 0.f;
+    for (int w = 0; w < p.kw; ++w) v += redbuf[(w * NACC + e_t) * 256 + (tid & 255)];
+    if (e_ok) {
+      if (ln) v = rstat[e_row * 2 + 1] * (v - rstat[e_row * 2] * e_u);
+      v += e_bias;
+      if (p.act == 1) v = gelu_new_fx(v);
+      if (p.res) v += e_res;
+      p.y[e_addr] = v;
+    }
+  }
+}
+
+void gemv_fx_plan(int N, int K, int rows, int* ntw, int* kw) {
+  const int kc16 = cdiv(K, 16), ntiles = cdiv(N, 16), MT = cdiv(rows, 16);
+  int k = 16;
+  while (k > 1 && kc16 < k) k >>= 1;
+  static const int ntw_min_tiles = getenv("IDXTTS_FX_NTW2_TILES") ? atoi(getenv("IDXTTS_FX_NTW2_TILES")) : 200;
+  static const int kw_cap = getenv("IDXTTS_FX_KW") ? atoi(getenv("IDXTTS_FX_KW")) : 16;
+  while (k > kw_cap) k >>= 1;
+  *kw = k;
+  *ntw = (MT == 1 && ntiles >= ntw_min_tiles) ? 2 : 1;     // wide layers: one activation fragment feeds two column tiles
+}
+
+int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t stream) {
+  IDX_CHECK(w.wp && a.xf && a.y, "null pointer");
+  IDX_CHECK(a.rows > 0 && a.rows <= 64, "1..64 rows");
+  IDX_CHECK((reinterpret_cast<uintptr_t>(a.xf) & 15) == 0, "x alignment");
+  if (a.colsum) IDX_CHECK(w.K % 16 == 0, "folded LayerNorm needs K % 16 == 0");
+  if (a.y_frag) IDX_CHECK(w.N % 16 == 0, "fragment-image output needs N % 16 == 0");
+  GemvFXP p;
+  p.xf = a.xf; p.wp = w.wp; p.bias = a.bias; p.colsum = a.colsum; p.ln_eps = a.ln_eps;
+  p.res = a.res; p.y = a.y; p.y_frag = a.y_frag; p.ldy = a.ldy;
+  p.rows = a.rows; p.N = w.N; p.K = w.K; p.kc16 = cdiv(w.K, 16); p.ntiles = cdiv(w.N, 16);
+  int ntw = 1;
+  gemv_fx_plan(w.N, w.K, a.rows, &ntw, &p.kw);
+  p.cps = cdiv(p.kc16, p.kw);
+  p.act = a.act; p.dbg = a.dbg;
+  const int MT = cdiv(a.rows, 16);
+  const int nacc = MT * ntw;
+  const int threads = std::max(64 * p.kw, 256 * nacc);      // one epilogue thread per output element of the workgroup
+  IDX_CHECK(threads <= 1024, "workgroup size");
+  const size_t lds = (size_t)(p.kw * nacc * 256 + p.kw * MT * 32 + MT * 32) * sizeof(float);
+  dim3 grid(cdiv(p.ntiles, ntw));
+  const double flops = 2.0 * a.rows * (double)w.N * w.K;
+  const double bytes = 4.0 * ((double)w.N * w.K + (double)a.rows * w.N * (a.res ? 2.0 : 1.0) + (double)a.rows * w.K);
+  ProfScope prof(PROF_GEMV16, stream, flops, bytes);
+#define LAUNCH(MTV, NTWV)                                                                                                 \
+  {                                                                                                                       \
+    static bool attr_set = false;                                                                                         \
+    if (!attr_set) {                                                                                                      \
+      IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_fx_kernel<MTV, NTWV>),                               \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                               \
+      attr_set = true;                                                                                                    \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((gemv_fx_kernel<MTV, NTWV>), grid, dim3(threads), lds, stream, p);                                 \
+  }
+  if (MT == 1 && ntw == 2) LAUNCH(1, 2)
+  else if (MT == 1) LAUNCH(1, 1) else if (MT == 2) LAUNCH(2, 1) else if (MT == 3) LAUNCH(3, 1) else LAUNCH(4, 1)
+#undef LAUNCH
+  IDX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace idxtts

@@ -13,7 +13,9 @@ namespace idxtts {
 struct GPTLayer {
   const float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
   LinearWeights attn_l, proj_l, fc_l, fc2_l;     // MFMA-32x32 packed (prefill / latent pass)
-  Gemv16Weights attn_g, proj_g, fc_g, fc2_g;     // stream-order packed (decode)
+  Gemv16Weights attn_g, proj_g, fc_g, fc2_g;     // stream-order packed (decode); attn_g / fc_g carry diag(ln_g) folded in
+  const float *attn_u = nullptr, *attn_c = nullptr;   // folded LayerNorm 1: colsum(diag(g) W), b . W + bias
+  const float *fc_u = nullptr, *fc_c = nullptr;       // folded LayerNorm 2
 };
 
 struct GPTModel : ModelBase {
@@ -23,15 +25,15 @@ struct GPTModel : ModelBase {
   Gemv16Weights head_g;
   const float* head_b = nullptr;
   const float *mel_emb = nullptr, *text_emb = nullptr, *mel_pos = nullptr, *text_pos = nullptr;
-  int ks_attn = 1, ks_proj = 1, ks_fc = 1, ks_fc2 = 1, ks_head = 1;
   hipStream_t own_stream = nullptr;
   ~GPTModel() override { if (own_stream) (void)hipStreamDestroy(own_stream); }
 
   struct Buffers {
     float *x, *h, *qkv, *att, *ff;            // [B*S][..] prefill / latent activations
     float *kcache, *vcache; int Smax;         // [L][B][H][Smax][64] each
-    float *xd, *hd, *attd;                    // [B][d] decode residual / normed / attention output
-    float *slab_a, *slab_b;                   // split-K partial slabs
+    float *xd, *hd, *attd, *ffd;              // decode residual / final-normed / attention output / mlp hidden: A-fragment images
+    float *qkvd, *logits;                     // [B][3d], [B][V] row-major
+    size_t frag_off, frag_bytes;              // the fragment-image region (zeroed once per generate: padding rows stay 0)
     unsigned char* seen; int *finished, *cur_tok, *kstart;
     DecodeState* state;
     size_t bytes;
@@ -43,7 +45,7 @@ struct GPTModel : ModelBase {
   Buffers carve(void* ws, int B, int S, int max_new) const;
   size_t workspace_bytes(int B, int S, int max_new) const;
   int layer_full(int li, const Buffers& w, int B, int S, const int* kstart, bool store_kv, hipStream_t st);
-  int head_and_sample(const Buffers& w, int B, const RowsNormArgs& norm_in, float penalty, long long* codes, int codes_ld,
+  int head_and_sample(const Buffers& w, int B, const float* x, int ldx, bool x_frag, float penalty, long long* codes, int codes_ld,
                       float* logits_out, hipStream_t st);
   int decode_step(const Buffers& w, int B, float penalty, long long* codes, int codes_ld, float* logits_base, hipStream_t st);
   int generate(const float* inputs_embeds, const int* pad_left_host, int B, int P, int max_new, float penalty, long long* codes,

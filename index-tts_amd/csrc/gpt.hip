@@ -47,8 +47,11 @@ static int upload(std::map<std::string, HostTensor>& t, DeviceArena& arena, cons
 }
 
 // HF Conv1D weight [K][N] -> both packed forms
+// ln_g / ln_b (host, [K]) non-null: the decode copy gets the LayerNorm in front of it folded in (gemv_fx.hip):
+//   W' = diag(g) W (packed), u = colsum(W'), c = b . W + bias
 static int make_proj(std::map<std::string, HostTensor>& t, DeviceArena& arena, const std::string& prefix, int K, int N,
-                     LinearWeights* lw, Gemv16Weights* gw) {
+                     LinearWeights* lw, Gemv16Weights* gw, const HostTensor* ln_g = nullptr, const HostTensor* ln_b = nullptr,
+                     const float** u_out = nullptr, const float** c_out = nullptr) {
   HostTensor* w = nullptr;
   if (need(t, prefix + ".weight", {K, N}, &w)) return 1;
   std::vector<float> buf(linear_packed_floats(N, K));
@@ -68,7 +71,30 @@ static int make_proj(std::map<std::string, HostTensor>& t, DeviceArena& arena, c
     lw->wp16 = d16;
   }
   buf.assign(gemv16_packed_floats(N, K), 0.0f);
-  pack_gemv16_kn(buf.data(), w->data.data(), K, N);
+  if (ln_g) {
+    HostTensor* bias = nullptr;
+    if (need(t, prefix + ".bias", {N}, &bias)) return 1;
+    std::vector<float> wf((size_t)K * N), u(N), c(N);
+    std::vector<double> ud(N, 0.0), cd(N, 0.0);
+    for (int k = 0; k < K; ++k) {
+      const float g = ln_g->data[k];
+      const double b = ln_b->data[k];
+      for (int n = 0; n < N; ++n) {
+        const float wv = w->data[(size_t)k * N + n];
+        const float wg = g * wv;
+        wf[(size_t)k * N + n] = wg;
+        ud[n] += (double)wg;
+        cd[n] += b * (double)wv;
+      }
+    }
+    for (int n = 0; n < N; ++n) { u[n] = (float)ud[n]; c[n] = (float)(cd[n] + (double)bias->data[n]); }
+    pack_gemv16_kn(buf.data(), wf.data(), K, N);
+    float *du = nullptr, *dc = nullptr;
+    if (arena.upload(u.data(), u.size(), &du) || arena.upload(c.data(), c.size(), &dc)) return 1;
+    *u_out = du; *c_out = dc;
+  } else {
+    pack_gemv16_kn(buf.data(), w->data.data(), K, N);
+  }
   if (arena.upload(buf.data(), buf.size(), &d)) return 1;
   gw->wp = d; gw->N = N; gw->K = K;
   return 0;
@@ -84,9 +110,12 @@ int GPTModel::finalize(std::map<std::string, HostTensor>& t, DeviceArena& arena)
     const std::string p = "gpt.h." + std::to_string(i);
     if (upload(t, arena, p + ".ln_1.weight", {d}, &L.ln1_g) || upload(t, arena, p + ".ln_1.bias", {d}, &L.ln1_b)) return 1;
     if (upload(t, arena, p + ".ln_2.weight", {d}, &L.ln2_g) || upload(t, arena, p + ".ln_2.bias", {d}, &L.ln2_b)) return 1;
-    if (make_proj(t, arena, p + ".attn.c_attn", d, 3 * d, &L.attn_l, &L.attn_g)) return 1;
+    HostTensor *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+    if (need(t, p + ".ln_1.weight", {d}, &g1) || need(t, p + ".ln_1.bias", {d}, &b1)) return 1;
+    if (need(t, p + ".ln_2.weight", {d}, &g2) || need(t, p + ".ln_2.bias", {d}, &b2)) return 1;
+    if (make_proj(t, arena, p + ".attn.c_attn", d, 3 * d, &L.attn_l, &L.attn_g, g1, b1, &L.attn_u, &L.attn_c)) return 1;
     if (make_proj(t, arena, p + ".attn.c_proj", d, d, &L.proj_l, &L.proj_g)) return 1;
-    if (make_proj(t, arena, p + ".mlp.c_fc", d, f, &L.fc_l, &L.fc_g)) return 1;
+    if (make_proj(t, arena, p + ".mlp.c_fc", d, f, &L.fc_l, &L.fc_g, g2, b2, &L.fc_u, &L.fc_c)) return 1;
     if (make_proj(t, arena, p + ".mlp.c_proj", f, d, &L.fc2_l, &L.fc2_g)) return 1;
   }
   if (upload(t, arena, "gpt.ln_f.weight", {d}, &lnf_g) || upload(t, arena, "gpt.ln_f.bias", {d}, &lnf_b)) return 1;
@@ -104,11 +133,6 @@ int GPTModel::finalize(std::map<std::string, HostTensor>& t, DeviceArena& arena)
   if (upload(t, arena, "text_embedding.weight", {cfg.number_text_tokens + 1, d}, &text_emb)) return 1;
   if (upload(t, arena, "mel_pos_embedding.emb.weight", {cfg.mel_pos_len, d}, &mel_pos)) return 1;
   if (upload(t, arena, "text_pos_embedding.emb.weight", {cfg.text_pos_len, d}, &text_pos)) return 1;
-  ks_attn = gemv16_plan_ksplit(3 * d, d);
-  ks_proj = gemv16_plan_ksplit(d, d);
-  ks_fc = gemv16_plan_ksplit(f, d);
-  ks_fc2 = gemv16_plan_ksplit(d, f);
-  ks_head = gemv16_plan_ksplit(V, d);
   return 0;
 }
 
@@ -138,17 +162,15 @@ GPTModel::Buffers GPTModel::carve(void* ws, int B, int S, int max_new) const {
   const size_t cache = (size_t)L * B * cfg.heads * b.Smax * 64;
   b.kcache = c.take<float>(cache);
   b.vcache = c.take<float>(cache);
-  b.xd = c.take<float>((size_t)B * d);
-  b.hd = c.take<float>((size_t)B * d);
-  b.attd = c.take<float>((size_t)B * d);
-  size_t slab = 0;
-  slab = std::max(slab, (size_t)ks_attn * B * 3 * d);
-  slab = std::max(slab, (size_t)ks_proj * B * d);
-  slab = std::max(slab, (size_t)ks_fc * B * 4 * d);
-  slab = std::max(slab, (size_t)ks_fc2 * B * d);
-  slab = std::max(slab, (size_t)ks_head * B * V);
-  b.slab_a = c.take<float>(slab);
-  b.slab_b = c.take<float>(slab);
+  // decode activations as A-fragment images (frag_index, common.h); one contiguous region so it can be zeroed in one go
+  b.xd = c.take<float>(frag_image_floats(B, d));
+  b.frag_off = c.off - frag_image_floats(B, d) * sizeof(float);
+  b.hd = c.take<float>(frag_image_floats(B, d));
+  b.attd = c.take<float>(frag_image_floats(B, d));
+  b.ffd = c.take<float>(frag_image_floats(B, 4 * d));
+  b.frag_bytes = c.off - b.frag_off;
+  b.qkvd = c.take<float>((size_t)B * 3 * d);
+  b.logits = c.take<float>((size_t)B * V);
   b.seen = c.take<unsigned char>((size_t)B * V);
   b.finished = c.take<int>(B);
   b.cur_tok = c.take<int>(B);
@@ -197,68 +219,53 @@ int GPTModel::layer_full(int li, const Buffers& w, int B, int S, const int* ksta
   return 0;
 }
 
-// head on B rows: ln_f -> final_norm -> mel_head (split-K slab) -> greedy sampler
-int GPTModel::head_and_sample(const Buffers& w, int B, const RowsNormArgs& norm_in, float penalty, long long* codes, int codes_ld,
-                              float* logits_out, hipStream_t st) {
-  const int d = cfg.model_dim, V = cfg.number_mel_codes;
-  RowsNormArgs n = norm_in;
-  n.y = w.hd; n.ld_y = d; n.M = B; n.d = d; n.mode = NORM_LN_LN;
-  n.g1 = lnf_g; n.b1 = lnf_b; n.g2 = fn_g; n.b2 = fn_b;
+// head on B rows: ln_f -> final_norm (one rows_norm launch, output as fragment images) -> mel_head -> greedy sampler
+int GPTModel::head_and_sample(const Buffers& w, int B, const float* x, int ldx, bool x_frag, float penalty, long long* codes,
+                              int codes_ld, float* logits_out, hipStream_t st) {
+  const int V = cfg.number_mel_codes, d = cfg.model_dim;
+  RowsNormArgs n;
+  n.x_in = x; n.ld_in = ldx; n.in_frag = x_frag ? 1 : 0; n.y = w.hd; n.ld_y = d; n.y_frag = 1; n.M = B; n.d = d;
+  n.mode = NORM_LN_LN; n.g1 = lnf_g; n.b1 = lnf_b; n.g2 = fn_g; n.b2 = fn_b;
   if (rows_norm_forward(n, st)) return 1;
-  Gemv16Args hv;
-  hv.x = w.hd; hv.ldx = d; hv.ypart = w.slab_b; hv.rows = B; hv.ksplit = ks_head;
-  if (gemv16_forward(head_g, hv, st)) return 1;
+  GemvFXArgs hv;
+  hv.xf = w.hd; hv.rows = B; hv.bias = head_b; hv.y = w.logits; hv.ldy = V;
+  if (gemv_fx_forward(head_g, hv, st)) return 1;
   SampleArgs s;
-  s.part = w.slab_b; s.parts = ks_head; s.part_rows = B; s.bias = head_b; s.logits_out = logits_out;
+  s.part = w.logits; s.parts = 1; s.part_rows = B; s.bias = nullptr; s.logits_out = logits_out;
   s.seen = w.seen; s.finished = w.finished; s.codes = codes; s.codes_ld = codes_ld; s.cur_tok = w.cur_tok;
   s.st = w.state; s.B = B; s.V = V; s.stop_token = cfg.stop_mel_token; s.penalty = penalty;
   return sample_greedy_forward(s, st);
 }
 
-// one autoregressive step for all B rows (replayable: no host-dependent arguments)
+// one autoregressive step for all B rows (replayable: no host-dependent arguments); 5 launches per layer, every
+// activation a fragment image:  c_attn [LN1 folded] -> attention -> c_proj (+x, in place) -> c_fc [LN2 folded, gelu_new]
+// -> mlp.c_proj (+x, in place)
 int GPTModel::decode_step(const Buffers& w, int B, float penalty, long long* codes, int codes_ld, float* logits_base,
                           hipStream_t st) {
-  const int d = cfg.model_dim, f = 4 * d;
+  const int d = cfg.model_dim;
   const size_t per_layer = (size_t)B * cfg.heads * w.Smax * 64;
   if (embed_step(w.xd, B, d, mel_emb, mel_pos, w.cur_tok, w.state, st)) return 1;
   for (int li = 0; li < cfg.layers; ++li) {
     const GPTLayer& L = layers[li];
-    // LN1; for li > 0 this also folds the previous layer's mlp.c_proj: x += bias + sum_s slab
-    RowsNormArgs n1;
-    n1.x_in = w.xd; n1.ld_in = d; n1.y = w.hd; n1.ld_y = d; n1.M = B; n1.d = d; n1.mode = NORM_LN; n1.g1 = L.ln1_g; n1.b1 = L.ln1_b;
-    if (li > 0) {
-      n1.add_bias = layers[li - 1].fc2_l.bias; n1.partials = w.slab_b; n1.num_partials = ks_fc2; n1.partial_rows = B; n1.ld_partial = d;
-      n1.x_out = w.xd; n1.ld_out = d;
-    }
-    if (rows_norm_forward(n1, st)) return 1;
-    Gemv16Args qa;
-    qa.x = w.hd; qa.ldx = d; qa.ypart = w.slab_a; qa.rows = B; qa.ksplit = ks_attn;
-    if (gemv16_forward(L.attn_g, qa, st)) return 1;
+    GemvFXArgs qa;      // qkv = c_attn(LN1(x)) + b, row-major for the attention kernel
+    qa.xf = w.xd; qa.rows = B; qa.colsum = L.attn_u; qa.bias = L.attn_c; qa.y = w.qkvd; qa.ldy = 3 * d;
+    if (gemv_fx_forward(L.attn_g, qa, st)) return 1;
     DecodeAttnArgs da;
-    da.qkv_part = w.slab_a; da.parts = ks_attn; da.part_rows = B; da.qkv_bias = L.attn_l.bias;
+    da.qkv_part = w.qkvd; da.parts = 1; da.part_rows = B; da.qkv_bias = nullptr;
     da.kcache = w.kcache + li * per_layer; da.vcache = w.vcache + li * per_layer; da.out = w.attd; da.kstart = w.kstart;
     da.st = w.state; da.B = B; da.H = cfg.heads; da.Smax = w.Smax; da.d = d; da.scale = 0.125f;
     if (decode_attn_forward(da, st)) return 1;
-    Gemv16Args pa;
-    pa.x = w.attd; pa.ldx = d; pa.ypart = w.slab_b; pa.rows = B; pa.ksplit = ks_proj;
-    if (gemv16_forward(L.proj_g, pa, st)) return 1;
-    RowsNormArgs n2;
-    n2.x_in = w.xd; n2.ld_in = d; n2.add_bias = L.proj_l.bias; n2.partials = w.slab_b; n2.num_partials = ks_proj; n2.partial_rows = B;
-    n2.ld_partial = d; n2.x_out = w.xd; n2.ld_out = d; n2.y = w.hd; n2.ld_y = d; n2.M = B; n2.d = d; n2.mode = NORM_LN;
-    n2.g1 = L.ln2_g; n2.b1 = L.ln2_b;
-    if (rows_norm_forward(n2, st)) return 1;
-    Gemv16Args fa;
-    fa.x = w.hd; fa.ldx = d; fa.ypart = w.slab_a; fa.rows = B; fa.ksplit = ks_fc;
-    if (gemv16_forward(L.fc_g, fa, st)) return 1;
-    Gemv16Args fb;     // input = gelu_new(sum_s slab_a + c_fc bias), fused into the staging prologue
-    fb.xpart = w.slab_a; fb.xparts = ks_fc; fb.xpart_rows = B; fb.ld_xpart = f; fb.xbias = L.fc_l.bias; fb.xact = 1;
-    fb.ypart = w.slab_b; fb.rows = B; fb.ksplit = ks_fc2;
-    if (gemv16_forward(L.fc2_g, fb, st)) return 1;
+    GemvFXArgs pa;      // x += c_proj(attn) + b  (in place: a thread reads and writes only its own element of x)
+    pa.xf = w.attd; pa.rows = B; pa.bias = L.proj_l.bias; pa.res = w.xd; pa.y = w.xd; pa.y_frag = 1;
+    if (gemv_fx_forward(L.proj_g, pa, st)) return 1;
+    GemvFXArgs fa;      // ff = gelu_new(c_fc(LN2(x)) + b)
+    fa.xf = w.xd; fa.rows = B; fa.colsum = L.fc_u; fa.bias = L.fc_c; fa.act = 1; fa.y = w.ffd; fa.y_frag = 1;
+    if (gemv_fx_forward(L.fc_g, fa, st)) return 1;
+    GemvFXArgs fb;      // x += mlp.c_proj(ff) + b
+    fb.xf = w.ffd; fb.rows = B; fb.bias = L.fc2_l.bias; fb.res = w.xd; fb.y = w.xd; fb.y_frag = 1;
+    if (gemv_fx_forward(L.fc2_g, fb, st)) return 1;
   }
-  RowsNormArgs nf;    // last layer's mlp.c_proj folded into the head norm
-  nf.x_in = w.xd; nf.ld_in = d; nf.add_bias = layers.back().fc2_l.bias; nf.partials = w.slab_b; nf.num_partials = ks_fc2;
-  nf.partial_rows = B; nf.ld_partial = d;
-  if (head_and_sample(w, B, nf, penalty, codes, codes_ld, logits_base, st)) return 1;
+  if (head_and_sample(w, B, w.xd, d, true, penalty, codes, codes_ld, logits_base, st)) return 1;
   return advance_state(w.state, st);
 }
 
@@ -286,6 +293,7 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
   for (int b = 0; b < B; ++b) IDX_CHECK(kstart[b] >= 0 && kstart[b] < P, "pad_left out of range");
   IDX_HIP(hipMemcpyAsync(w.kstart, kstart.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
   IDX_HIP(hipMemsetAsync(w.finished, 0, B * sizeof(int), st));
+  IDX_HIP(hipMemsetAsync(static_cast<char*>(ws) + w.frag_off, 0, w.frag_bytes, st));   // padding rows of the fragment images
   // input_ids of the reference = fake prefix of 1s + start_mel_token: both count for the repetition penalty
   std::vector<unsigned char> seen((size_t)B * V, 0);
   for (int b = 0; b < B; ++b) { seen[(size_t)b * V + 1] = 1; seen[(size_t)b * V + cfg.start_mel_token] = 1; }
@@ -313,9 +321,8 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
   for (int li = 0; li < cfg.layers; ++li)
     if (layer_full(li, w, B, S, w.kstart, true, st)) return 1;
   {
-    RowsNormArgs nl;
-    nl.x_in = w.x + (size_t)(S - 1) * d; nl.ld_in = S * d;   // last position of every row
-    if (head_and_sample(w, B, nl, penalty, codes, max_new, logits_out, st)) return 1;
+    // last position of every row
+    if (head_and_sample(w, B, w.x + (size_t)(S - 1) * d, S * d, false, penalty, codes, max_new, logits_out, st)) return 1;
     if (advance_state(w.state, st)) return 1;
   }
 

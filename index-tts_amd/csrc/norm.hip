@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void rows_norm_kernel(const RowsNormArgs p) {
     const int e = tid + (i << 8);
     float a = 0.0f;
     if (e < d) {
-      if (xin) a = xin[e];
+      if (xin) a = p.in_frag ? p.x_in[frag_index(m, e, d >> 4)] : xin[e];
       if (p.add_bias) a += p.add_bias[e];
     }
     v[i] = a;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void rows_norm_kernel(const RowsNormArgs p) {
     for (int i = 0; i < nper; ++i) { const int e = tid + (i << 8); if (e < d) v[i] = (v[i] - mean2) * rstd2 * p.g2[e] + p.b2[e]; }
   }
 #pragma unroll
-  for (int i = 0; i < nper; ++i) { const int e = tid + (i << 8); if (e < d) p.y[(size_t)m * p.ld_y + e] = v[i]; }
+  for (int i = 0; i < nper; ++i) { const int e = tid + (i << 8); if (e < d) p.y[p.y_frag ? frag_index(m, e, d >> 4) : (size_t)m * p.ld_y + e] = v[i]; }
 }
 
 int rows_norm_forward(const RowsNormArgs& a, hipStream_t stream) {
@@ -159,6 +159,7 @@ int rows_norm_forward(const RowsNormArgs& a, hipStream_t stream) {
   if (a.mode == NORM_LN_LN) IDX_CHECK(a.g2 && a.b2, "second LayerNorm needs weight and bias");
   if (a.mode == NORM_ADA_RMS) IDX_CHECK(a.g1 && (!a.mod_a == !a.mod_b), "RMSNorm needs a weight (and both or no modulation vectors)");
   if (a.mode == NORM_MOD_LN) IDX_CHECK(a.mod_a && a.mod_b, "modulated LN needs shift and scale");
+  if (a.in_frag || a.y_frag) IDX_CHECK((a.mode == NORM_LN || a.mode == NORM_LN_LN) && a.d % 16 == 0 && a.in_rows_per_batch == 0, "fragment-image I/O: LayerNorm modes, d % 16 == 0");
   const double bytes = 4.0 * a.M * (double)a.d * (1.0 + a.num_partials + (a.x_out ? 1 : 0) + (a.y ? 1 : 0));
   ProfScope prof(PROF_ROWS_NORM, stream, 0.0, bytes);
   const int nper = (a.d + 255) / 256;

@@ -237,3 +237,20 @@ def test_latent_pass_split_bf16_vs_oracle(device):
     finally:
         _lib.set_gemm_mode(_lib.GEMM_BF16X3)
     assert errs["f32"] <= 1e-4 and errs["bf16x3"] <= 2e-3 and errs["bf16x3"] > 0
+
+
+def test_greedy_batch_above_16_rows_vs_oracle(device):
+    """B = 20 utterances: the decode GEMVs run with two row tiles (and the un-fused LayerNorm path)."""
+    from indextts_amd.gpt import UnifiedVoice
+    from oracle import gpt as og
+    cfg = GPTConfig.tiny()
+    w = weights.synth_gpt_weights(cfg, tag="t/gpt/b20")
+    uv = UnifiedVoice(w, cfg, device=device)
+    tw = {k: torch.from_numpy(v) for k, v in w.items()}
+    B, L = 20, 8
+    lat = torch.from_numpy(synth.uniform("t/gpt/b20/lat", (B, cfg.cond_latents, cfg.model_dim), 0.5))
+    emo = torch.from_numpy(synth.uniform("t/gpt/b20/emo", (B, cfg.model_dim), 0.3))
+    text = torch.from_numpy(synth.integers("t/gpt/b20/text", (B, L), 2, cfg.number_text_tokens))
+    codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=12, repetition_penalty=10.0)
+    ref = og.generate_greedy(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, 12, 10.0)
+    assert np.array_equal(codes.cpu().numpy(), ref.numpy())

@@ -27,6 +27,8 @@ def main(src, dst):
         with open(path) as f:
             for r in csv.DictReader(f):
                 k = short(r["Kernel_Name"])
+                if os.environ.get("SUMMARIZE_BY_GRID"):     # split one kernel's launches by launch geometry
+                    k += " grid=%s,%s wg=%s" % (r.get("Grid_Size_X", "?"), r.get("Grid_Size_Y", "?"), r.get("Workgroup_Size_X", "?"))
                 agg[k][0] += 1
                 agg[k][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         out["kernel_trace"] = {k: {"calls": v[0], "total_ms": v[1] / 1e6, "avg_us": v[1] / v[0] / 1e3} for k, v in agg.items()}
