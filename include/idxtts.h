@@ -111,6 +111,12 @@ int idxtts_linear_destroy(idxtts_linear* lin);
 int idxtts_attention_fwd(const float* q, const float* k, const float* v, float* o, long q_batch_stride, int q_token_stride,
                          long kv_batch_stride, int kv_token_stride, long o_batch_stride, int o_token_stride, int B, int H,
                          int Sq, int Sk, int causal, const int* kstart, const int* kend, float scale, void* stream);
+/* Same contract on the bf16 matrix core with split operands (x = hi + lo, three bf16 MFMAs per product, fp32
+ * accumulation; relative error ~2^-16).  Used by the s2mel DiT and the GPT latent pass when the GEMM mode is
+ * IDXTTS_GEMM_BF16X3; the KV-cache-building prefill always runs the exact-fp32 form above. */
+int idxtts_attention_bf16x3_fwd(const float* q, const float* k, const float* v, float* o, long q_batch_stride, int q_token_stride,
+                         long kv_batch_stride, int kv_token_stride, long o_batch_stride, int o_token_stride, int B, int H,
+                         int Sq, int Sk, int causal, const int* kstart, const int* kend, float scale, void* stream);
 /* y = LayerNorm(x) * gamma + beta over the last dim (eps), rows of length d. */
 int idxtts_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, int M, int d, float eps, void* stream);
 

@@ -13,6 +13,7 @@ struct AttnArgs {
   const int* kstart = nullptr;    // [B] first valid key (left padding), or null
   const int* kend = nullptr;      // [B] one past the last valid key (right padding / x_lens), or null
   float scale = 0.125f;
+  int split_bf16 = 0;             // 1: split-bf16 products (3 bf16 MFMAs each, ~2^-16 relative) instead of exact-fp32 MFMAs
 };
 
 int flash_attn_forward(const AttnArgs& a, hipStream_t stream);

@@ -176,6 +176,221 @@ __global__ __launch_bounds__(256) void flash_attn_f32_kernel(const AttnArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Split-bf16 variant for the compute-bound non-decode passes (s2mel DiT, GPT latent pass): same tiling and the same
+// "query = lane" online softmax, but both products run on v_mfma_f32_32x32x16_bf16 with every fp32 operand written as
+// hi + lo (bf16 each) and three MFMAs per product (hi*hi + hi*lo + lo*hi, fp32 accumulation: relative error ~2^-16):
+// 24 bf16 MFMAs (768 cycles) per 32 x 32 (query, key) tile instead of 64 f32 MFMAs (4096 cycles).
+//   S^T = K . Q^T : K rows (hi/lo planes, 144-byte rows) are ds_read_b128 A operands, Q^T lives in registers (pre-scaled by
+//                   scale * log2 e so the softmax uses v_exp_f32 directly);
+//   O^T += V^T . P^T : P stays in the accumulator registers; register r of lane half h is key (r&3) + 8(r>>2) + 4h, i.e.
+//                   the 8 k-slots a lane feeds to MFMA t2 are keys 16 t2 + 4h + {0..3, 8..11}; V is kept ROW-major in LDS
+//                   (coalesced 8-byte stores) and read as the matching A operand with two ds_read_b64_tr_b16 transposing
+//                   reads (4 consecutive keys x 16 d each; 192-byte rows keep the four rows of a read on disjoint banks).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KB16 = 144;          // K row bytes: 64 bf16 + 8 pad
+constexpr int VB16 = 192;          // V row bytes: 64 bf16 + 32 pad
+constexpr int ABUF = 2 * 32 * KB16 + 2 * 32 * VB16;     // hi/lo K, hi/lo V of one 32-key tile: 21504 B
+
+__device__ __forceinline__ void split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
+  hi = __builtin_convertvector(v, bf16x4);
+  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+}
+
+__global__ __launch_bounds__(256) void flash_attn_bf16x3_kernel(const AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * ABUF];
+
+  const int qblk = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int h = lane >> 5, j = lane & 31;
+  const int q0 = qblk * 128 + wave * 32;
+  const int qi = q0 + j;
+  const int kstart = p.kstart ? p.kstart[b] : 0;
+  const int kend = p.kend ? min(p.kend[b], p.Sk) : p.Sk;
+  int k_hi = kend;
+  if (p.causal) k_hi = min(k_hi, qblk * 128 + 128);
+  const int k_lo = kstart & ~31;
+  const int ntiles = k_hi > k_lo ? (k_hi - k_lo + 31) >> 5 : 0;
+
+  const float* qb = p.q + (size_t)b * p.q_bs + hd * 64;
+  const float* kb = p.k + (size_t)b * p.k_bs + hd * 64;
+  const float* vb = p.v + (size_t)b * p.v_bs + hd * 64;
+
+  // Q^T fragments (B operand): lane (query j, half h) holds Q[qi][16c + 8h + e], e = 0..7, for the four 16-d chunks c
+  bf16x8 qh[4], ql[4];
+  {
+    const bool ok = qi < p.Sq;
+    const float* qrow = qb + (size_t)(ok ? qi : 0) * p.q_ts;
+    const float sc = p.scale * 1.4426950408889634f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, bq = a;
+      if (ok) {
+        a = *reinterpret_cast<const f32x4*>(qrow + 16 * c + 8 * h);
+        bq = *reinterpret_cast<const f32x4*>(qrow + 16 * c + 8 * h + 4);
+      }
+      bf16x4 ah, al, bh, bl;
+      split4(a * sc, ah, al);
+      split4(bq * sc, bh, bl);
+      qh[c] = __builtin_shufflevector(ah, bh, 0, 1, 2, 3, 4, 5, 6, 7);
+      ql[c] = __builtin_shufflevector(al, bl, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  }
+
+  f32x4 kr[2], vr[2];
+  auto load_kv = [&](int tile) {
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const int idx = tid + 256 * l;
+      const int row = idx >> 4, c4 = idx & 15;
+      const int key = k_lo + tile * 32 + row;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+      if (key < p.Sk) {
+        a = *reinterpret_cast<const f32x4*>(kb + (size_t)key * p.k_ts + c4 * 4);
+        c = *reinterpret_cast<const f32x4*>(vb + (size_t)key * p.v_ts + c4 * 4);
+      }
+      kr[l] = a;
+      vr[l] = c;
+    }
+  };
+  auto store_kv = [&](int buf) {
+    char* base = smem + buf * ABUF;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const int idx = tid + 256 * l;
+      const int row = idx >> 4, c4 = idx & 15;
+      bf16x4 hi, lo;
+      split4(kr[l], hi, lo);
+      *reinterpret_cast<bf16x4*>(base + row * KB16 + c4 * 8) = hi;
+      *reinterpret_cast<bf16x4*>(base + 32 * KB16 + row * KB16 + c4 * 8) = lo;
+      split4(vr[l], hi, lo);
+      *reinterpret_cast<bf16x4*>(base + 64 * KB16 + row * VB16 + c4 * 8) = hi;
+      *reinterpret_cast<bf16x4*>(base + 64 * KB16 + 32 * VB16 + row * VB16 + c4 * 8) = lo;
+    }
+  };
+
+  f32x16 o[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
+  float m_run = NEG_BIG, l_run = 0.0f;
+
+  // byte offsets of this lane's operand reads inside a tile buffer
+  const int k_off = j * KB16 + 16 * h;                                  // + 32 * c per 16-d chunk (+ 32*KB16 for lo)
+  // transposing V read: lane 4q+p of a 16-lane group addresses row (key) q, columns 4p..4p+3 of the group's 16 columns
+  const int v_off = 64 * KB16 + (4 * h + ((lane & 15) >> 2)) * VB16 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
+  if (ntiles > 0) {
+    load_kv(0);
+    store_kv(0);
+  }
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const bool has_next = tile + 1 < ntiles;
+    if (has_next) load_kv(tile + 1);
+    const char* tb = smem + (tile & 1) * ABUF;
+    const int key0 = k_lo + tile * 32;
+    const bool wave_active = !(p.causal && key0 > q0 + 31) && q0 < p.Sq;      // wave-uniform
+    if (wave_active) {
+      // ---- S^T = K . Q^T ----
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(tb + k_off + 32 * c);
+        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(tb + 32 * KB16 + k_off + 32 * c);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[c], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[c], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[c], s, 0, 0, 0);
+      }
+      // ---- mask (boundary tiles only: wave-uniform test) + online softmax in the log2 domain ----
+      const bool need_mask = key0 < kstart || key0 + 32 > kend || (p.causal && key0 + 31 > q0);
+      float mx = NEG_BIG;
+      if (need_mask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const bool ok = key >= kstart && key < kend && (!p.causal || key <= qi);
+          s[r] = ok ? s[r] : NEG_BIG;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float psum = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float pv = __builtin_amdgcn_exp2f(s[r] - m_new);
+        if (need_mask) pv = s[r] <= -1e29f ? 0.0f : pv;
+        s[r] = pv;
+        psum += pv;
+      }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      // ---- P^T operands: registers 8 t2 .. 8 t2 + 7 are the k-slots of MFMA t2 ----
+      bf16x8 ph[2], pl[2];
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const f32x4 a = {s[8 * t2 + 0], s[8 * t2 + 1], s[8 * t2 + 2], s[8 * t2 + 3]};
+        const f32x4 c = {s[8 * t2 + 4], s[8 * t2 + 5], s[8 * t2 + 6], s[8 * t2 + 7]};
+        bf16x4 ah, al, ch, cl;
+        split4(a, ah, al);
+        split4(c, ch, cl);
+        ph[t2] = __builtin_shufflevector(ah, ch, 0, 1, 2, 3, 4, 5, 6, 7);
+        pl[t2] = __builtin_shufflevector(al, cl, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+      // ---- O^T += V^T . P^T ----
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const char* va = tb + v_off + 16 * t2 * VB16 + 64 * t;
+          typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+          const bf16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(va));
+          const bf16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(va + 8 * VB16));
+          const bf16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(va + 32 * VB16));
+          const bf16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(va + 40 * VB16));
+          const bf16x8 vh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+          const bf16x8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[t2], o[t], 0, 0, 0);
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[t2], o[t], 0, 0, 0);
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[t2], o[t], 0, 0, 0);
+        }
+    }
+    if (has_next) store_kv((tile + 1) & 1);
+    __syncthreads();
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv_l = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+  float* stage = reinterpret_cast<float*>(smem) + wave * (32 * 65);
+  static_assert(4 * 32 * 65 * 4 <= 2 * ABUF, "output staging must fit in the K/V tiles");
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dd = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      stage[j * 65 + dd] = o[t][r] * inv_l;
+    }
+  __syncthreads();
+  float* ob = p.o + (size_t)b * p.o_bs + hd * 64;
+#pragma unroll
+  for (int it = 0; it < 32; ++it) {
+    const int qq = q0 + it;
+    if (qq < p.Sq) ob[(size_t)qq * p.o_ts + lane] = stage[it * 65 + lane];
+  }
+}
+
 int flash_attn_forward(const AttnArgs& a, hipStream_t stream) {
   if (a.B == 0 || a.H == 0 || a.Sq == 0) return 0;
   IDX_CHECK(a.q && a.k && a.v && a.o, "null pointer");
@@ -186,7 +401,8 @@ int flash_attn_forward(const AttnArgs& a, hipStream_t stream) {
   const double flops = 4.0 * a.B * a.H * (double)a.Sq * a.Sk * 64 * (a.causal ? 0.5 : 1.0);
   const double bytes = 4.0 * a.B * a.H * 64.0 * (2.0 * a.Sq + 2.0 * a.Sk);
   ProfScope prof(PROF_FLASH_ATTN, stream, flops, bytes);
-  hipLaunchKernelGGL(flash_attn_f32_kernel, grid, dim3(256), 0, stream, a);
+  if (a.split_bf16) hipLaunchKernelGGL(flash_attn_bf16x3_kernel, grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(flash_attn_f32_kernel, grid, dim3(256), 0, stream, a);
   IDX_LAUNCH_CHECK();
   return 0;
 }

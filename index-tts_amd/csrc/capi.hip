@@ -243,6 +243,19 @@ int idxtts_attention_fwd(const float* q, const float* k, const float* v, float* 
   API_END
 }
 
+int idxtts_attention_bf16x3_fwd(const float* q, const float* k, const float* v, float* o, long q_batch_stride, int q_token_stride,
+                         long kv_batch_stride, int kv_token_stride, long o_batch_stride, int o_token_stride, int B, int H,
+                         int Sq, int Sk, int causal, const int* kstart, const int* kend, float scale, void* stream) {
+  API_BEGIN
+  AttnArgs a;
+  a.q = q; a.k = k; a.v = v; a.o = o;
+  a.q_bs = q_batch_stride; a.k_bs = a.v_bs = kv_batch_stride; a.o_bs = o_batch_stride;
+  a.q_ts = q_token_stride; a.k_ts = a.v_ts = kv_token_stride; a.o_ts = o_token_stride;
+  a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.causal = causal; a.kstart = kstart; a.kend = kend; a.scale = scale; a.split_bf16 = 1;
+  return flash_attn_forward(a, static_cast<hipStream_t>(stream));
+  API_END
+}
+
 int idxtts_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, int M, int d, float eps, void* stream) {
   API_BEGIN
   RowsNormArgs n;

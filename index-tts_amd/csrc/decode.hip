@@ -44,33 +44,44 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
   float* kc = p.kcache + (size_t)(b * p.H + h) * 16 * Smax * 4;
   float* vc = p.vcache + (size_t)(b * p.H + h) * Smax * 64;
 
-  // ---- q, k, v of the new token: bias + split-K slab sum (waves 0,1,2 take q,k,v; loads of all slabs in flight together) ----
+  // Everything that does not depend on the new token's q is put in flight first: this thread's first key (16 x 16 B,
+  // coalesced across threads) and its first 8 value rows of the P.V phase; the kernel is a chain of dependent
+  // HBM / L2 round trips, so the cache streams have to overlap the qkv fetch and the softmax barriers.
+  const int ks = p.kstart ? p.kstart[b] : 0;
+  const int grp = tid >> 4, l16 = tid & 15;
+  const int s_first = ks + tid;
+  f32x4 kk0[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    kk0[i] = s_first < pos ? *reinterpret_cast<const f32x4*>(kc + ((size_t)i * Smax + s_first) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 vpre[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int sj = ks + grp + 16 * j;
+    vpre[j] = sj < pos ? *reinterpret_cast<const f32x4*>(vc + (size_t)sj * 64 + 4 * l16) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // ---- q, k, v of the new token (waves 0,1,2 take q,k,v) ----
   if (tid < 192) {
     const int which = tid >> 6, dd = tid & 63;
     const int col = which * d + h * 64 + dd;
     const float* row = p.qkv_part + (size_t)b * 3 * d + col;
     const size_t sst = (size_t)p.part_rows * 3 * d;
     float acc = p.qkv_bias ? p.qkv_bias[col] : 0.0f;
-    int s = 0;
-    for (; s + 4 <= p.parts; s += 4) {
-      const float t0 = row[(size_t)(s + 0) * sst], t1 = row[(size_t)(s + 1) * sst], t2 = row[(size_t)(s + 2) * sst], t3 = row[(size_t)(s + 3) * sst];
-      acc = (((acc + t0) + t1) + t2) + t3;
-    }
-    for (; s < p.parts; ++s) acc += row[(size_t)s * sst];
+    for (int s = 0; s < p.parts; ++s) acc += row[(size_t)s * sst];
     if (which == 0) qs[dd] = acc * p.scale;
     else if (which == 1) { knew[dd] = acc; kc[((size_t)(dd >> 2) * Smax + pos) * 4 + (dd & 3)] = acc; }
     else { vnew[dd] = acc; vc[(size_t)pos * 64 + dd] = acc; }
   }
   __syncthreads();
 
-  const int ks = p.kstart ? p.kstart[b] : 0;
   f32x4 q4[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) q4[i] = *reinterpret_cast<const f32x4*>(&qs[4 * i]);
 
-  // ---- scores: one key per thread (16 coalesced 16-byte loads each) ----
+  // ---- scores: one key per thread ----
   float mx = -1e30f;
-  for (int s = ks + tid; s <= pos; s += 256) {
+  for (int s = s_first; s <= pos; s += 256) {
     float dot = 0.f;
     if (s == pos) {
 #pragma unroll
@@ -78,6 +89,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
         const f32x4 kk = *reinterpret_cast<const f32x4*>(&knew[4 * i]);
         dot += q4[i][0] * kk[0] + q4[i][1] * kk[1] + q4[i][2] * kk[2] + q4[i][3] * kk[3];
       }
+    } else if (s == s_first) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dot += q4[i][0] * kk0[i][0] + q4[i][1] * kk0[i][1] + q4[i][2] * kk0[i][2] + q4[i][3] * kk0[i][3];
     } else {
       f32x4 kk[16];
 #pragma unroll
@@ -93,7 +107,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float sum = 0.f;
-  for (int s = ks + tid; s <= pos; s += 256) {
+  for (int s = s_first; s <= pos; s += 256) {
     const float e = expf(pr[s] - mx);
     pr[s] = e;
     sum += e;
@@ -104,23 +118,32 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
   const float l = red[4] + red[5] + red[6] + red[7];
 
   // ---- P.V : 16 key groups x 16 lanes; a lane owns 4 head dims (one 16-byte load per key, 256-byte rows coalesced),
-  //      4 keys in flight per lane; group g takes keys ks+g, ks+g+16, ... ----
-  const int grp = tid >> 4, l16 = tid & 15;
+  //      8 keys in flight per lane; group g takes keys ks+g, ks+g+16, ... ----
+  const f32x4 vn4 = *reinterpret_cast<const f32x4*>(&vnew[4 * l16]);
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-  int s = ks + grp;
-  for (; s + 48 < pos; s += 64) {
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(vc + (size_t)s * 64 + 4 * l16);
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(vc + (size_t)(s + 16) * 64 + 4 * l16);
-    const f32x4 v2 = *reinterpret_cast<const f32x4*>(vc + (size_t)(s + 32) * 64 + 4 * l16);
-    const f32x4 v3 = *reinterpret_cast<const f32x4*>(vc + (size_t)(s + 48) * 64 + 4 * l16);
-    a0 += pr[s] * v0;
-    a1 += pr[s + 16] * v1;
-    a2 += pr[s + 32] * v2;
-    a3 += pr[s + 48] * v3;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int sj = ks + grp + 16 * j;
+    if (sj <= pos) {
+      const f32x4 t = pr[sj] * (sj == pos ? vn4 : vpre[j]);
+      if ((j & 3) == 0) a0 += t; else if ((j & 3) == 1) a1 += t; else if ((j & 3) == 2) a2 += t; else a3 += t;
+    }
   }
-  for (; s <= pos; s += 16) {
-    const f32x4 vv = (s == pos) ? *reinterpret_cast<const f32x4*>(&vnew[4 * l16]) : *reinterpret_cast<const f32x4*>(vc + (size_t)s * 64 + 4 * l16);
-    a0 += pr[s] * vv;
+  for (int sb = ks + grp + 128; sb <= pos; sb += 128) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int sj = sb + 16 * j;
+      v[j] = sj < pos ? *reinterpret_cast<const f32x4*>(vc + (size_t)sj * 64 + 4 * l16) : vn4;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int sj = sb + 16 * j;
+      if (sj <= pos) {
+        const f32x4 t = pr[sj] * v[j];
+        if ((j & 3) == 0) a0 += t; else if ((j & 3) == 1) a1 += t; else if ((j & 3) == 2) a2 += t; else a3 += t;
+      }
+    }
   }
   *reinterpret_cast<f32x4*>(&outp[grp * 64 + 4 * l16]) = (a0 + a1) + (a2 + a3);
   __syncthreads();

@@ -49,13 +49,22 @@ static inline float bf2f(uint16_t b) {
   return f;
 }
 
-size_t linear_bf16x3_packed_bytes(int N, int K) { return (size_t)cdiv(N, 128) * cdiv(K, 32) * WTILE_BYTES; }
+// the pack holds two images: the padded LDS-image tiles of the register-staged kernels below, then the
+// [hl][K/16][Npad][16] planes of the LDS-DMA kernel (gemm_bf16x3_v2.hip)
+size_t linear_planes_bytes(int N, int K);
+void pack_linear_planes(void* dst, const float* w, int N, int K);
+bool gemm_bf16x3_v2_enabled();
+int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w, const GemmArgs& a, hipStream_t stream, double flops,
+                           double bytes);
+static size_t tiles_bytes(int N, int K) { return (size_t)cdiv(N, 128) * cdiv(K, 32) * WTILE_BYTES; }
+size_t linear_bf16x3_packed_bytes(int N, int K) { return tiles_bytes(N, K) + linear_planes_bytes(N, K); }
 
 // w: [N][K] fp32 -> [N/128][K/32][hl][128][40] bf16
 void pack_linear_bf16x3(void* dst, const float* w, int N, int K) {
   uint16_t* o = static_cast<uint16_t*>(dst);
   const int NB = cdiv(N, 128), KS = cdiv(K, 32);
-  std::memset(o, 0, linear_bf16x3_packed_bytes(N, K));
+  std::memset(o, 0, tiles_bytes(N, K));
+  pack_linear_planes(static_cast<char*>(dst) + tiles_bytes(N, K), w, N, K);
   for (int nb = 0; nb < NB; ++nb)
     for (int ks = 0; ks < KS; ++ks) {
       uint16_t* tile = o + ((size_t)nb * KS + ks) * (2 * TILE_HALF);
@@ -377,6 +386,8 @@ int gemm_bf16x3_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t s
   IDX_CHECK(grid < (1ll << 31), "grid size");
   const double flops = 2.0 * a.M * (double)w.N * w.K;
   const double bytes = 4.0 * ((double)a.M * w.K + (double)w.N * w.K + (double)a.M * w.N * (a.res ? 2.0 : 1.0));
+  if (gemm_bf16x3_v2_enabled() && a.M >= 4096 && w.N >= 192 && w.K % 16 == 0 && (a.taps <= 1 || (w.K / a.taps) % 16 == 0))
+    return gemm_bf16x3_v2_forward(p, static_cast<const char*>(w.wp16) + tiles_bytes(w.N, w.K), w, a, stream, flops, bytes);
   static int tile_sel = getenv("IDXTTS_GEMM_TILE") ? atoi(getenv("IDXTTS_GEMM_TILE")) : 2;   // 0: 128x128, 1: 256x128, 2: 256x256
   if (tile_sel >= 1 && a.M >= 4096) {
     const bool paired = a.act == ACT_SWIGLU || a.act == ACT_GATE;

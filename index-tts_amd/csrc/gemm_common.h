@@ -87,6 +87,97 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmKP& p, f32x16 (&acc)[T
   }
 }
 
+// Workgroup epilogue through LDS: the accumulators of one wave-row (a slab of TM*32 rows x BN columns) are transposed
+// through LDS so that every global access of the epilogue is row-contiguous: a lane owns 4 adjacent columns (one 16-byte
+// bias load for the whole tile, 16-byte residual loads and stores; a 256-column row is ONE 1-KiB wave store) and every
+// per-row quantity (bounds, row mask) is wave-uniform.  The direct form above issues TM*TN*16 scattered dword stores per
+// lane from fully unrolled code (tens of thousands of instructions: 40-50 % of a K = 512 GEMM's time on MI355X).
+//   WMW x WNW waves, wave (wm, wn) holds rows wm*TM*32.., packed columns wn*TN*32..; lds: >= TM*32 * (BN + 8) floats.
+// All waves of the workgroup must call it (it synchronises); LDS must not be in use by anyone (no DMA in flight).
+template <int WMW, int WNW, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmKP& p, f32x16 (&acc)[TM][TN], float* lds, int row_base, int col_base,
+                                                  int wm, int wn, int wave, int lane) {
+  constexpr int BN = WNW * TN * 32, SLAB = TM * 32, NW = WMW * WNW;
+  constexpr int RS = BN + 8;                    // +8 floats: the two row groups a wave writes (h = 0/1: rows +4) land on disjoint banks
+  const bool paired = p.act == ACT_SWIGLU || p.act == ACT_GATE;
+  const int h = lane >> 5, j = lane & 31;
+  const bool vec_ok = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) &&
+                      (!p.res || (((p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0)));
+  for (int slab = 0; slab < WMW; ++slab) {
+    __syncthreads();
+    if (wm == slab) {
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            lds[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * RS + wn * TN * 32 + nt * 32 + j] = acc[mt][nt][r];
+    }
+    __syncthreads();
+    const int lpr = paired ? BN / 8 : BN / 4;   // lanes per row
+    const int rpi = 64 / lpr;                   // rows per wave-instruction
+    const int sub = lane / lpr, c = lane - sub * lpr;
+    // column operands of this lane are the same for every row
+    int n_out, nb0, nb1 = 0;                    // first output column, bias index (and second bias index for pairs)
+    const float* src_off;
+    if (paired) {
+      const int g = c >> 3, cc = (c & 7) * 4;   // 64-column packed group, offset inside its 32 outputs
+      nb0 = col_base + g * 64 + cc; nb1 = nb0 + 32;
+      n_out = ((col_base + g * 64) >> 1) + cc;
+      src_off = lds + g * 64 + cc;
+    } else {
+      nb0 = col_base + c * 4;
+      n_out = nb0;
+      src_off = lds + c * 4;
+    }
+    const int n_lim = paired ? (p.N >> 1) : p.N;
+    const bool col_ok = nb0 < p.N;
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (p.bias && col_ok) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (nb0 + e < p.N) b0[e] = p.bias[nb0 + e];
+        if (paired && nb1 + e < p.N) b1[e] = p.bias[nb1 + e];
+      }
+    }
+    for (int rr = wave * (SLAB / NW) + sub; rr < (wave + 1) * (SLAB / NW); rr += rpi) {
+      const int m = row_base + slab * SLAB + rr;
+      if (m >= p.M || !col_ok) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(src_off + rr * RS) + b0;
+      if (paired) {
+        const f32x4 lin = *reinterpret_cast<const f32x4*>(src_off + rr * RS + 32) + b1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = p.act == ACT_SWIGLU ? (v[e] / (1.0f + expf(-v[e]))) * lin[e] : tanhf(v[e]) * (1.0f / (1.0f + expf(-lin[e])));
+      } else if (p.act != ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act);
+      }
+      v *= p.out_scale;
+      bool masked = false;
+      if (p.row_len) {
+        const int sb = m / p.seq_len;
+        masked = (m - sb * p.seq_len) >= p.row_len[sb];
+      }
+      float* dst = p.y + (size_t)m * p.ldy + n_out;
+      if (vec_ok && n_out + 3 < n_lim) {
+        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + n_out);
+        if (masked) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n_out + e < n_lim) {
+            float o = v[e];
+            if (p.res) o += p.res[(size_t)m * p.ldr + n_out + e];
+            dst[e] = masked ? 0.0f : o;
+          }
+      }
+    }
+  }
+}
+
 // 128x128 workgroup tile, 2x2 waves of 64x64
 __device__ __forceinline__ void gemm_epilogue(const GemmKP& p, f32x16 (&acc)[2][2], int bm, int bn, int wm, int wn, int h, int j) {
   gemm_epilogue_t<2, 2>(p, acc, bm * 128 + wm * 64, bn * 128 + wn * 64, h, j);

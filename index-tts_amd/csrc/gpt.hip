@@ -203,6 +203,7 @@ int GPTModel::layer_full(int li, const Buffers& w, int B, int S, const int* ksta
   a.q_bs = a.k_bs = a.v_bs = (long)S * 3 * d; a.o_bs = (long)S * d;
   a.q_ts = a.k_ts = a.v_ts = 3 * d; a.o_ts = d;
   a.B = B; a.H = cfg.heads; a.Sq = S; a.Sk = S; a.causal = 1; a.kstart = kstart; a.scale = 0.125f;
+  a.split_bf16 = !store_kv && get_gemm_mode() == GEMM_BF16X3;      // the cache-building prefill stays exact fp32
   if (flash_attn_forward(a, st)) return 1;
   GemmArgs p;
   p.x = w.att; p.ldx = d; p.y = w.x; p.ldy = d; p.res = w.x; p.ldr = d; p.M = M;

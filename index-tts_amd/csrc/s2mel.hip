@@ -353,6 +353,7 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
     a.q_bs = a.k_bs = a.v_bs = (long)T * 3 * D; a.o_bs = (long)T * D;
     a.q_ts = a.k_ts = a.v_ts = 3 * D; a.o_ts = D;
     a.B = N2; a.H = c.num_heads; a.Sq = T; a.Sk = T; a.causal = 0; a.kend = w.lens2; a.scale = 0.125f;
+    a.split_bf16 = get_gemm_mode() == GEMM_BF16X3;
     if (flash_attn_forward(a, st)) return 1;
     if (gemm(B.wo, w.att, D, w.hmid, D, M, st, ACT_NONE, h, D)) return 1;           // h + attention(...)
     if (ada(w.hmid, B.ffn_g, 2 * i + 1)) return 1;

@@ -19,7 +19,7 @@ SYMBOLS = [
     "idxtts_ctx_load_tensor", "idxtts_ctx_finalize", "idxtts_ctx_destroy",
     "idxtts_bigvgan_create", "idxtts_bigvgan_workspace_bytes", "idxtts_bigvgan_fwd",
     "idxtts_profile_enable", "idxtts_profile_num_kernels", "idxtts_profile_kernel_name", "idxtts_profile_read",
-    "idxtts_linear_create", "idxtts_linear_fwd", "idxtts_linear_destroy", "idxtts_attention_fwd", "idxtts_layernorm_fwd",
+    "idxtts_linear_create", "idxtts_linear_fwd", "idxtts_linear_destroy", "idxtts_attention_fwd", "idxtts_attention_bf16x3_fwd", "idxtts_layernorm_fwd",
     "idxtts_gpt_create", "idxtts_gpt_workspace_bytes", "idxtts_gpt_embed", "idxtts_gpt_generate", "idxtts_gpt_latent",
     "idxtts_s2mel_create", "idxtts_s2mel_cond_workspace_bytes", "idxtts_s2mel_prepare_cond",
     "idxtts_s2mel_cfm_workspace_bytes", "idxtts_s2mel_cfm", "idxtts_set_gemm_mode", "idxtts_get_gemm_mode",
@@ -84,6 +84,7 @@ def load() -> ctypes.CDLL:
     lib.idxtts_linear_destroy.argtypes = [c_void_p]
     lib.idxtts_attention_fwd.argtypes = [c_void_p] * 4 + [c_long, c_int, c_long, c_int, c_long, c_int, c_int, c_int, c_int, c_int,
                                                           c_int, c_void_p, c_void_p, c_float, c_void_p]
+    lib.idxtts_attention_bf16x3_fwd.argtypes = lib.idxtts_attention_fwd.argtypes
     lib.idxtts_layernorm_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]
     lib.idxtts_gpt_create.argtypes = [POINTER(GPTConfigC), POINTER(c_void_p)]
     lib.idxtts_gpt_workspace_bytes.argtypes = [c_void_p, c_int, c_int, c_int]

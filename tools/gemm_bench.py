@@ -37,6 +37,11 @@ def bench(M, N, K, mode, iters=20):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) >= 5:      # one shape, one mode (for rocprofv3 --pmc passes): M N K mode [iters]
+        M, N, K, mode = (int(v) for v in sys.argv[1:5])
+        r = bench(M, N, K, mode, int(sys.argv[5]) if len(sys.argv) > 5 else 5)
+        print(f"M={M} N={N} K={K} mode={mode}: {r[0]:.3f} ms {r[1]:.1f} TF", flush=True)
+        sys.exit(0)
     shapes = [(50208, 1536, 512), (50208, 3072, 512), (50208, 512, 1536), (50208, 512, 512), (50208, 128, 512), (50208, 512, 864),
               (50208, 1024, 2560), (13488, 3840, 1280), (13488, 1280, 5120), (8192, 8192, 1024)]
     for (M, N, K) in shapes:
