@@ -13,6 +13,7 @@ struct AttnArgs {
   const int* kstart = nullptr;    // [B] first valid key (left padding), or null
   const int* kend = nullptr;      // [B] one past the last valid key (right padding / x_lens), or null
   float scale = 0.125f;
+  void* o_planes = nullptr;       // split_bf16 only: write the output as split-bf16 planes over rows b*Sq + q, columns head*64 + d (o may be null)
   int split_bf16 = 0;             // 1: split-bf16 products (3 bf16 MFMAs each, ~2^-16 relative) instead of exact-fp32 MFMAs
 };
 

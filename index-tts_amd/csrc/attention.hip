@@ -383,17 +383,28 @@ __global__ __launch_bounds__(256) void flash_attn_bf16x3_kernel(const AttnArgs p
       stage[j * 65 + dd] = o[t][r] * inv_l;
     }
   __syncthreads();
-  float* ob = p.o + (size_t)b * p.o_bs + hd * 64;
+  float* ob = p.o ? p.o + (size_t)b * p.o_bs + hd * 64 : nullptr;
+  __bf16* const o_hi = static_cast<__bf16*>(p.o_planes);
+  __bf16* const o_lo = o_hi ? o_hi + plane_elems(p.B * p.Sq, p.H * 64) : nullptr;
 #pragma unroll
   for (int it = 0; it < 32; ++it) {
     const int qq = q0 + it;
-    if (qq < p.Sq) ob[(size_t)qq * p.o_ts + lane] = stage[it * 65 + lane];
+    if (qq < p.Sq) {
+      const float val = stage[it * 65 + lane];
+      if (ob) ob[(size_t)qq * p.o_ts + lane] = val;
+      if (o_hi) {
+        const __bf16 hi = (__bf16)val;
+        const size_t o = plane_index(b * p.Sq + qq, hd * 64 + lane, p.B * p.Sq);
+        o_hi[o] = hi;
+        o_lo[o] = (__bf16)(val - (float)hi);
+      }
+    }
   }
 }
 
 int flash_attn_forward(const AttnArgs& a, hipStream_t stream) {
   if (a.B == 0 || a.H == 0 || a.Sq == 0) return 0;
-  IDX_CHECK(a.q && a.k && a.v && a.o, "null pointer");
+  IDX_CHECK(a.q && a.k && a.v && (a.o || (a.o_planes && a.split_bf16)), "null pointer");
   IDX_CHECK(a.head_dim == 64, "head_dim must be 64");
   IDX_CHECK((a.q_ts & 3) == 0 && (a.k_ts & 3) == 0 && (a.v_ts & 3) == 0 && (a.q_bs & 3) == 0 && (a.k_bs & 3) == 0 && (a.v_bs & 3) == 0,
             "q/k/v strides must be multiples of 4 floats");

@@ -25,6 +25,10 @@ int fail(const char* file, int line, const std::string& msg);
 __host__ __device__ static inline size_t frag_index(int row, int k, int kc16) {
   return ((((size_t)(row >> 4) * kc16 + (k >> 4)) * 64 + ((k & 15) >> 2) * 16 + (row & 15)) << 2) + (k & 3);
 }
+// Split-bf16 GEMM operands (gemm_bf16x3_v2.hip): activation x[rows][K] fp32 as two bf16 planes (hi, lo = x - hi), each
+// [K/16][rows][16]: a 16-k chunk of all rows is one contiguous run.  Producers may write them directly.
+__host__ __device__ static inline size_t plane_index(int row, int k, int rows) { return ((size_t)(k >> 4) * rows + row) * 16 + (k & 15); }
+__host__ __device__ static inline size_t plane_elems(int rows, int K) { return (size_t)((K + 15) / 16) * rows * 16; }    // per plane; lo plane follows hi
 static inline size_t frag_image_floats(int rows, int K) { return (size_t)((rows + 15) / 16) * ((K + 15) / 16) * 256; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -23,6 +23,11 @@ void pack_linear_kn(float* dst, const float* w_kn, int K, int N);
 struct GemmArgs {
   const float* x = nullptr; int ldx = 0;      // [M][K], row stride ldx floats
   float* y = nullptr; int ldy = 0;            // [M][N] (SWIGLU: [M][N/2])
+  // split-bf16 planes (plane_index, common.h; lo plane at + plane_elems(M, channels)), rows = M:
+  //   x_planes: the input already split (by its producer) -- x may then be null; only the LDS-DMA kernel takes it
+  //   y_planes: the epilogue also writes its output as planes for the next GEMM; y may then be null
+  const void* x_planes = nullptr;
+  void* y_planes = nullptr;
   const float* res = nullptr; int ldr = 0;    // optional residual added after the activation
   // optional per-row-group modulation of the OUTPUT (adaLN etc. are handled by the norm kernels, not here)
   int M = 0;
@@ -47,5 +52,7 @@ void set_gemm_mode(int mode);
 int get_gemm_mode();
 // dispatches on the mode above
 int gemm_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t stream);
+// true when gemm_forward would run this shape on the LDS-DMA split-bf16 kernel (the only consumer / producer of planes)
+bool gemm_uses_planes(const LinearWeights& w, const GemmArgs& a);
 
 }  // namespace idxtts

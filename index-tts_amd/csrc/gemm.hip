@@ -183,7 +183,8 @@ int gemm_tn_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t strea
   }
   if (a.row_len) IDX_CHECK(a.seq_len > 0, "row_len needs seq_len");
   GemmKP p;
-  p.x = a.x; p.wp = w.wp; p.bias = w.bias; p.res = a.res; p.y = a.y;
+  IDX_CHECK(a.x && a.y && !a.y_planes, "the fp32 GEMM takes and produces fp32 rows only");
+  p.x = a.x; p.wp = w.wp; p.bias = w.bias; p.res = a.res; p.y = a.y; p.y_hi = p.y_lo = nullptr;
   p.M = a.M; p.N = w.N; p.K = w.K; p.ldx = a.ldx; p.ldy = a.ldy; p.ldr = a.ldr;
   p.kc16 = cdiv(w.K, 16);
   p.mtiles = cdiv(a.M, 128);
@@ -214,6 +215,10 @@ static int g_gemm_mode = GEMM_BF16X3;
 void set_gemm_mode(int mode) { g_gemm_mode = mode == GEMM_F32 ? GEMM_F32 : GEMM_BF16X3; }
 int get_gemm_mode() { return g_gemm_mode; }
 
+bool gemm_bf16x3_uses_v2(const LinearWeights& w, const GemmArgs& a);
+bool gemm_uses_planes(const LinearWeights& w, const GemmArgs& a) {
+  return g_gemm_mode == GEMM_BF16X3 && w.wp16 && a.M >= 256 && gemm_bf16x3_uses_v2(w, a);
+}
 int gemm_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t stream) {
   if (g_gemm_mode == GEMM_BF16X3 && w.wp16 && a.M >= 256) return gemm_bf16x3_forward(w, a, stream);
   return gemm_tn_forward(w, a, stream);

@@ -54,8 +54,12 @@ static inline float bf2f(uint16_t b) {
 size_t linear_planes_bytes(int N, int K);
 void pack_linear_planes(void* dst, const float* w, int N, int K);
 bool gemm_bf16x3_v2_enabled();
+bool gemm_bf16x3_uses_v2(const LinearWeights& w, const GemmArgs& a);
 int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w, const GemmArgs& a, hipStream_t stream, double flops,
                            double bytes);
+bool gemm_bf16x3_uses_v2(const LinearWeights& w, const GemmArgs& a) {
+  return gemm_bf16x3_v2_enabled() && w.wp16 && a.M >= 4096 && w.N >= 192 && w.K % 16 == 0 && (a.taps <= 1 || (w.K / a.taps) % 16 == 0);
+}
 static size_t tiles_bytes(int N, int K) { return (size_t)cdiv(N, 128) * cdiv(K, 32) * WTILE_BYTES; }
 size_t linear_bf16x3_packed_bytes(int N, int K) { return tiles_bytes(N, K) + linear_planes_bytes(N, K); }
 
@@ -359,11 +363,12 @@ static int launch_big(GemmKP p, const LinearWeights& w, const GemmArgs& a, hipSt
 }
 
 int gemm_bf16x3_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t stream) {
-  IDX_CHECK(w.wp16 && a.x && a.y, "null pointer (split-bf16 weights not packed?)");
+  IDX_CHECK(w.wp16 && (a.x || a.x_planes) && (a.y || a.y_planes), "null pointer (split-bf16 weights not packed?)");
   if (a.M == 0) return 0;
   IDX_CHECK(a.M > 0 && w.N > 0 && w.K > 0, "bad shape");
   IDX_CHECK((w.K & 3) == 0 && (a.ldx & 3) == 0, "K and ldx must be multiples of 4");
   IDX_CHECK((reinterpret_cast<uintptr_t>(a.x) & 15) == 0, "x must be 16-byte aligned");
+  if (a.x_planes || a.y_planes || !a.x || !a.y) IDX_CHECK(gemm_bf16x3_uses_v2(w, a), "operand planes are only understood by the LDS-DMA kernel (shape not eligible)");
   if (a.act == ACT_SWIGLU || a.act == ACT_GATE) IDX_CHECK((w.N & 63) == 0, "paired activations need N % 64 == 0");
   if (a.taps > 1) {
     IDX_CHECK(a.seq_len > 0 && a.M % a.seq_len == 0 && w.K % a.taps == 0 && ((w.K / a.taps) & 31) == 0, "conv mode shape");
@@ -371,7 +376,7 @@ int gemm_bf16x3_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t s
   }
   if (a.row_len) IDX_CHECK(a.seq_len > 0, "row_len needs seq_len");
   GemmKP p;
-  p.x = a.x; p.wp = reinterpret_cast<const float*>(w.wp16); p.bias = w.bias; p.res = a.res; p.y = a.y;
+  p.x = a.x; p.wp = reinterpret_cast<const float*>(w.wp16); p.bias = w.bias; p.res = a.res; p.y = a.y; p.y_hi = p.y_lo = nullptr;
   p.M = a.M; p.N = w.N; p.K = w.K; p.ldx = a.ldx; p.ldy = a.ldy; p.ldr = a.ldr;
   p.kc16 = cdiv(w.K, 16);
   p.mtiles = cdiv(a.M, 128);
@@ -386,7 +391,7 @@ int gemm_bf16x3_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t s
   IDX_CHECK(grid < (1ll << 31), "grid size");
   const double flops = 2.0 * a.M * (double)w.N * w.K;
   const double bytes = 4.0 * ((double)a.M * w.K + (double)w.N * w.K + (double)a.M * w.N * (a.res ? 2.0 : 1.0));
-  if (gemm_bf16x3_v2_enabled() && a.M >= 4096 && w.N >= 192 && w.K % 16 == 0 && (a.taps <= 1 || (w.K / a.taps) % 16 == 0))
+  if (gemm_bf16x3_uses_v2(w, a))
     return gemm_bf16x3_v2_forward(p, static_cast<const char*>(w.wp16) + tiles_bytes(w.N, w.K), w, a, stream, flops, bytes);
   static int tile_sel = getenv("IDXTTS_GEMM_TILE") ? atoi(getenv("IDXTTS_GEMM_TILE")) : 2;   // 0: 128x128, 1: 256x128, 2: 256x256
   if (tile_sel >= 1 && a.M >= 4096) {

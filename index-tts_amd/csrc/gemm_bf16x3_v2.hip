@@ -268,7 +268,7 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
   const int xk = a.taps > 1 ? w.K / a.taps : w.K;       // channels of the activation rows
   const size_t plane = (size_t)(xk / 16) * a.M * 16 * sizeof(__bf16);
   PlaneScratch& sc = g_scratch[stream];
-  if (sc.bytes < 2 * plane) {
+  if (!a.x_planes && sc.bytes < 2 * plane) {
     IDX_HIP(hipStreamSynchronize(stream));
     if (sc.ptr) IDX_HIP(hipFree(sc.ptr));
     sc.bytes = 2 * plane + (plane >> 2);
@@ -280,15 +280,21 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
     IDX_HIP(hipMemset(z, 0, 4096));
     g_zero_page = static_cast<const __bf16*>(z);
   }
-  __bf16* hi = static_cast<__bf16*>(sc.ptr);
-  __bf16* lo = hi + plane / sizeof(__bf16);
-  {
+  const __bf16* hi = a.x_planes ? static_cast<const __bf16*>(a.x_planes) : static_cast<const __bf16*>(sc.ptr);
+  const __bf16* lo = hi + plane / sizeof(__bf16);
+  if (!a.x_planes) {
     ProfScope prof(PROF_ELTWISE, stream, 0.0, 8.0 * a.M * (double)xk);
-    hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv(a.M, 64), cdiv(xk, 64)), dim3(256), 0, stream, a.x, a.ldx, a.M, xk, hi, lo);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv(a.M, 64), cdiv(xk, 64)), dim3(256), 0, stream, a.x, a.ldx, a.M, xk, const_cast<__bf16*>(hi), const_cast<__bf16*>(lo));
     IDX_LAUNCH_CHECK();
   }
   GemmV2P q;
   q.g = p;
+  if (a.y_planes) {
+    const int n_out = (a.act == ACT_SWIGLU || a.act == ACT_GATE) ? w.N / 2 : w.N;
+    IDX_CHECK(n_out % 16 == 0 && (a.ldy & 3) == 0, "output planes need N_out % 16 == 0");
+    q.g.y_hi = static_cast<__bf16*>(a.y_planes);
+    q.g.y_lo = q.g.y_hi + plane_elems(a.M, n_out);
+  }
   q.g.mtiles = cdiv(a.M, 256);
   q.g.mt8 = cdiv(q.g.mtiles, 8);
   q.g.nblocks = cdiv(w.N, 256);

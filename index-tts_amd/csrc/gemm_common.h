@@ -16,6 +16,7 @@ struct GemmKP {
   float out_scale;
   int taps, kc, seq_len, dil, pad_left, pad_mode;
   const int* row_len;
+  __bf16* y_hi; __bf16* y_lo;      // optional split-bf16 planes of the output ([N_out/16][M][16]); y may be null then
 };
 
 
@@ -164,14 +165,22 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmKP& p, f32x16 (&acc)
       if (vec_ok && n_out + 3 < n_lim) {
         if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + n_out);
         if (masked) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(dst) = v;
+        if (p.y) *reinterpret_cast<f32x4*>(dst) = v;
+        if (p.y_hi) {       // n_out % 4 == 0: the four columns share a 16-k chunk
+          typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+          const bf16x4_t hi = __builtin_convertvector(v, bf16x4_t);
+          const bf16x4_t lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4_t);
+          const size_t o = plane_index(m, n_out, p.M);
+          *reinterpret_cast<bf16x4_t*>(p.y_hi + o) = hi;
+          *reinterpret_cast<bf16x4_t*>(p.y_lo + o) = lo;
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (n_out + e < n_lim) {
             float o = v[e];
             if (p.res) o += p.res[(size_t)m * p.ldr + n_out + e];
-            dst[e] = masked ? 0.0f : o;
+            if (p.y) dst[e] = masked ? 0.0f : o;
           }
       }
     }

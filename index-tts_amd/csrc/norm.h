@@ -13,6 +13,7 @@ struct RowsNormArgs {
   const float* partials = nullptr; int num_partials = 0; int partial_rows = 0; int ld_partial = 0;
   float* x_out = nullptr; int ld_out = 0;       // optional write-back of x
   float* y = nullptr; int ld_y = 0;             // normalised output
+  void* y_planes = nullptr;                     // optional: y also/only as split-bf16 planes (plane_index, common.h; rows = M); y may be null
   int in_frag = 0, y_frag = 0;                  // x_in / y are A-fragment images over d (frag_index, common.h) instead of row-major
   int M = 0, d = 0;
   int mode = NORM_LN;

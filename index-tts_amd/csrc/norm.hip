@@ -41,6 +41,17 @@ __global__ __launch_bounds__(256) void rows_norm_kernel(const RowsNormArgs p) {
   __shared__ float red[4];
   const int m = blockIdx.x, tid = threadIdx.x, d = p.d;
   constexpr int nper = NPER;
+  __bf16* const y_hi = static_cast<__bf16*>(p.y_planes);
+  __bf16* const y_lo = y_hi ? y_hi + plane_elems(p.M, d) : nullptr;
+  auto put = [&](int e, float val) {      // normalised output: fp32 row and / or split-bf16 planes
+    if (p.y) p.y[p.y_frag ? frag_index(m, e, d >> 4) : (size_t)m * p.ld_y + e] = val;
+    if (y_hi) {
+      const __bf16 hi = (__bf16)val;
+      const size_t o = plane_index(m, e, p.M);
+      y_hi[o] = hi;
+      y_lo[o] = (__bf16)(val - (float)hi);
+    }
+  };
   float v[NPER];
   const float* xin = nullptr;
   if (p.x_in) {
@@ -88,7 +99,7 @@ __global__ __launch_bounds__(256) void rows_norm_kernel(const RowsNormArgs p) {
       if (e < d) p.x_out[(size_t)m * p.ld_out + e] = v[i];
     }
   }
-  if (p.mode == NORM_NONE || !p.y) {
+  if (p.mode == NORM_NONE || !(p.y || p.y_planes)) {
     if (p.y)
 #pragma unroll
       for (int i = 0; i < nper; ++i) { const int e = tid + (i << 8); if (e < d) p.y[(size_t)m * p.ld_y + e] = v[i]; }
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(256) void rows_norm_kernel(const RowsNormArgs p) {
       if (e < d) {
         float o = v[i] * r * p.g1[e];
         if (wm) o = wm[e] * o + bm[e];
-        p.y[(size_t)m * p.ld_y + e] = o;
+        put(e, o);
       }
     }
     return;
@@ -129,7 +140,7 @@ __global__ __launch_bounds__(256) void rows_norm_kernel(const RowsNormArgs p) {
 #pragma unroll
     for (int i = 0; i < nper; ++i) {
       const int e = tid + (i << 8);
-      if (e < d) p.y[(size_t)m * p.ld_y + e] = (v[i] - mean) * rstd * (1.0f + sc[e]) + sh[e];
+      if (e < d) put(e, (v[i] - mean) * rstd * (1.0f + sc[e]) + sh[e]);
     }
     return;
   }
@@ -148,7 +159,7 @@ __global__ __launch_bounds__(256) void rows_norm_kernel(const RowsNormArgs p) {
     for (int i = 0; i < nper; ++i) { const int e = tid + (i << 8); if (e < d) v[i] = (v[i] - mean2) * rstd2 * p.g2[e] + p.b2[e]; }
   }
 #pragma unroll
-  for (int i = 0; i < nper; ++i) { const int e = tid + (i << 8); if (e < d) p.y[p.y_frag ? frag_index(m, e, d >> 4) : (size_t)m * p.ld_y + e] = v[i]; }
+  for (int i = 0; i < nper; ++i) { const int e = tid + (i << 8); if (e < d) put(e, v[i]); }
 }
 
 int rows_norm_forward(const RowsNormArgs& a, hipStream_t stream) {

@@ -271,6 +271,7 @@ struct Carver2 {
 
 struct CfmBuffers {
   float *x_in, *ha, *hb, *hmid, *hn, *qkv, *att, *ff, *xres, *wn_x, *wn_acts, *wn_out, *vout, *condp, *xstate;
+  void *hn_p, *att_p, *ff_p, *acts_p;     // split-bf16 planes of hn / att / ff / wn_acts (producers write them for the next GEMM)
   std::vector<float*> skips;
   float *t1, *t1s, *mods, *fmod, *t2, *wnb, *tmp_steps;
   int *lens2, *plen;
@@ -293,6 +294,10 @@ static CfmBuffers carve_cfm(const S2MelModel& m, void* ws, int B, int T, int n_s
   b.att = k.take<float>(M2 * D);
   b.ff = k.take<float>(M2 * m.ffn);
   b.xres = k.take<float>(M2 * D);
+  b.hn_p = k.take<float>(M2 * std::max(D, Wh));      // 2 bf16 planes = 4 bytes per element
+  b.att_p = k.take<float>(M2 * D);
+  b.ff_p = k.take<float>(M2 * m.ffn);
+  b.acts_p = k.take<float>(M2 * Wh);
   b.wn_x = k.take<float>(M2 * Wh);
   b.wn_acts = k.take<float>(M2 * Wh);
   b.wn_out = k.take<float>(M2 * Wh);
@@ -315,10 +320,13 @@ static CfmBuffers carve_cfm(const S2MelModel& m, void* ws, int B, int T, int n_s
 
 size_t S2MelModel::cfm_workspace_bytes(int B, int T, int n_steps) const { return carve_cfm(*this, nullptr, B, T, n_steps).bytes; }
 
+// xp / yp: split-bf16 planes of the input / output (GemmArgs::x_planes / y_planes); with xp the fp32 x is not read,
+// with yp and y == nullptr no fp32 output is written
 static int gemm(const LinearWeights& w, const float* x, int ldx, float* y, int ldy, int M, hipStream_t st, int act = ACT_NONE,
-                const float* res = nullptr, int ldr = 0) {
+                const float* res = nullptr, int ldr = 0, const void* xp = nullptr, void* yp = nullptr) {
   GemmArgs a;
-  a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.M = M; a.act = act; a.res = res; a.ldr = ldr;
+  a.x = xp ? nullptr : x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.M = M; a.act = act; a.res = res; a.ldr = ldr;
+  a.x_planes = xp; a.y_planes = yp;
   return gemm_forward(w, a, st);
 }
 
@@ -327,9 +335,21 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
   const int D = c.hidden_dim, C = c.in_channels, Wh = c.wn_hidden, depth = c.depth, half = depth / 2;
   const int M = N2 * T, Win = 2 * C + D + c.style_dim;
   const float* mods = w.mods + (size_t)step * (2 * depth + 1) * 2 * D;
+  // Producer -> GEMM chaining: when the consumers run on the LDS-DMA split-bf16 kernel, hn / att / ff / wn_acts are
+  // written by their producers directly as bf16 hi/lo planes (same bytes as the fp32 row) and never exist in fp32.
+  bool chain = true;
+  {
+    GemmArgs pr;
+    pr.M = M;
+    const LinearWeights* used[] = {&m.blocks[0].wqkv, &m.blocks[0].wo, &m.blocks[0].w13, &m.blocks[0].w2, &m.skiplin_a, &m.final_lin,
+                                   &m.wn[0].skip};
+    for (const LinearWeights* lw : used) chain = chain && gemm_uses_planes(*lw, pr);
+  }
+  float* const hn_f = chain ? nullptr : w.hn;
+  void* const hn_p = chain ? w.hn_p : nullptr;
   auto ada = [&](const float* x, const float* g, int mod_idx) {
     RowsNormArgs n;
-    n.x_in = x; n.ld_in = D; n.y = w.hn; n.ld_y = D; n.M = M; n.d = D; n.mode = NORM_ADA_RMS; n.eps = c.norm_eps; n.g1 = g;
+    n.x_in = x; n.ld_in = D; n.y = hn_f; n.y_planes = hn_p; n.ld_y = D; n.M = M; n.d = D; n.mode = NORM_ADA_RMS; n.eps = c.norm_eps; n.g1 = g;
     n.mod_a = mods + (size_t)mod_idx * 2 * D; n.mod_b = n.mod_a + D; n.ld_mod = 0; n.rows_per_batch = 0;
     return rows_norm_forward(n, st);
   };
@@ -346,7 +366,7 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
       h = dst;
     }
     if (ada(h, B.attn_g, 2 * i)) return 1;
-    if (gemm(B.wqkv, w.hn, D, w.qkv, 3 * D, M, st)) return 1;
+    if (gemm(B.wqkv, w.hn, D, w.qkv, 3 * D, M, st, ACT_NONE, nullptr, 0, hn_p)) return 1;
     if (rotary_qk(w.qkv, M, c.num_heads, T, m.rope, st)) return 1;
     AttnArgs a;
     a.q = w.qkv; a.k = w.qkv + D; a.v = w.qkv + 2 * D; a.o = w.att;
@@ -354,18 +374,19 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
     a.q_ts = a.k_ts = a.v_ts = 3 * D; a.o_ts = D;
     a.B = N2; a.H = c.num_heads; a.Sq = T; a.Sk = T; a.causal = 0; a.kend = w.lens2; a.scale = 0.125f;
     a.split_bf16 = get_gemm_mode() == GEMM_BF16X3;
+    if (chain) { a.o = nullptr; a.o_planes = w.att_p; }
     if (flash_attn_forward(a, st)) return 1;
-    if (gemm(B.wo, w.att, D, w.hmid, D, M, st, ACT_NONE, h, D)) return 1;           // h + attention(...)
+    if (gemm(B.wo, w.att, D, w.hmid, D, M, st, ACT_NONE, h, D, chain ? w.att_p : nullptr)) return 1;           // h + attention(...)
     if (ada(w.hmid, B.ffn_g, 2 * i + 1)) return 1;
-    if (gemm(B.w13, w.hn, D, w.ff, m.ffn, M, st, ACT_SWIGLU)) return 1;
+    if (gemm(B.w13, w.hn, D, chain ? nullptr : w.ff, m.ffn, M, st, ACT_SWIGLU, nullptr, 0, hn_p, chain ? w.ff_p : nullptr)) return 1;
     float* dst = (i < half) ? w.skips[pushed] : ((h == w.ha) ? w.hb : w.ha);
-    if (gemm(B.w2, w.ff, m.ffn, dst, D, M, st, ACT_NONE, w.hmid, D)) return 1;      // out = h + ffn
+    if (gemm(B.w2, w.ff, m.ffn, dst, D, M, st, ACT_NONE, w.hmid, D, chain ? w.ff_p : nullptr)) return 1;      // out = h + ffn
     if (i < half) ++pushed;
     h = dst;
   }
   if (ada(h, m.final_g, 2 * depth)) return 1;
   // long skip: skip_linear(cat[x_res, x]) (diffusion_transformer.py:243-244); x rows live in x_in[:, :C]
-  if (gemm(m.skiplin_a, w.hn, D, w.hmid, D, M, st)) return 1;
+  if (gemm(m.skiplin_a, w.hn, D, w.hmid, D, M, st, ACT_NONE, nullptr, 0, hn_p)) return 1;
   if (gemm(m.skiplin_b, w.x_in, Win, w.xres, D, M, st, ACT_NONE, w.hmid, D)) return 1;
   if (gemm(m.conv1, w.xres, D, w.wn_x, Wh, M, st)) return 1;
   // WaveNet (wavenet.py:138-166)
@@ -377,16 +398,16 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
     LinearWeights in = W.in_gate;
     in.bias = w.wnb + ((size_t)step * L + l) * 2 * Wh;     // in_layer bias + g_l of this step, gate-packed
     GemmArgs g;
-    g.x = w.wn_x; g.ldx = Wh; g.y = w.wn_acts; g.ldy = Wh; g.M = M; g.act = ACT_GATE;
+    g.x = w.wn_x; g.ldx = Wh; g.y = chain ? nullptr : w.wn_acts; g.y_planes = chain ? w.acts_p : nullptr; g.ldy = Wh; g.M = M; g.act = ACT_GATE;
     g.taps = k; g.seq_len = T; g.dil = dil; g.pad_left = (k - 1) / 2 * dil; g.pad_mode = 1; g.row_len = w.lens2;
     if (gemm_forward(in, g, st)) return 1;
     if (W.has_res) {   // x = (x + res) * mask
       GemmArgs r;
-      r.x = w.wn_acts; r.ldx = Wh; r.y = w.wn_x; r.ldy = Wh; r.res = w.wn_x; r.ldr = Wh; r.M = M; r.seq_len = T; r.row_len = w.lens2;
+      r.x = chain ? nullptr : w.wn_acts; r.x_planes = chain ? w.acts_p : nullptr; r.ldx = Wh; r.y = w.wn_x; r.ldy = Wh; r.res = w.wn_x; r.ldr = Wh; r.M = M; r.seq_len = T; r.row_len = w.lens2;
       if (gemm_forward(W.res, r, st)) return 1;
     }
     GemmArgs s;        // output += skip ; the last layer's epilogue applies "* x_mask" to the finished sum
-    s.x = w.wn_acts; s.ldx = Wh; s.y = w.wn_out; s.ldy = Wh; s.M = M;
+    s.x = chain ? nullptr : w.wn_acts; s.x_planes = chain ? w.acts_p : nullptr; s.ldx = Wh; s.y = w.wn_out; s.ldy = Wh; s.M = M;
     if (l > 0) { s.res = w.wn_out; s.ldr = Wh; }
     if (l == L - 1) { s.seq_len = T; s.row_len = w.lens2; }
     if (gemm_forward(W.skip, s, st)) return 1;
@@ -394,11 +415,11 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
   if (gemm(m.res_proj, w.xres, D, w.hmid, Wh, M, st, ACT_NONE, w.wn_out, Wh)) return 1;
   {
     RowsNormArgs n;     // FinalLayer (diffusion_transformer.py:96-101)
-    n.x_in = w.hmid; n.ld_in = Wh; n.y = w.hn; n.ld_y = Wh; n.M = M; n.d = Wh; n.mode = NORM_MOD_LN; n.eps = 1e-6f;
+    n.x_in = w.hmid; n.ld_in = Wh; n.y = hn_f; n.y_planes = hn_p; n.ld_y = Wh; n.M = M; n.d = Wh; n.mode = NORM_MOD_LN; n.eps = 1e-6f;
     n.mod_a = w.fmod + (size_t)step * 2 * Wh; n.mod_b = n.mod_a + Wh; n.ld_mod = 0; n.rows_per_batch = 0;
     if (rows_norm_forward(n, st)) return 1;
   }
-  if (gemm(m.final_lin, w.hn, Wh, w.att, Wh, M, st)) return 1;
+  if (gemm(m.final_lin, w.hn, Wh, w.att, Wh, M, st, ACT_NONE, nullptr, 0, hn_p)) return 1;
   return gemm(m.conv2, w.att, Wh, w.vout, C, M, st);
 }
 
