@@ -23,8 +23,11 @@ struct GemvFXArgs {
   int act = 0;                                    // 0 none, 1 gelu_new
   const float* res = nullptr;                     // residual in the layout of y (may alias y)
   float* y = nullptr; int y_frag = 0; int ldy = 0;   // y_frag: fragment images over N, else row-major [rows][ldy]
+  int ksb = 1;                                    // > 1 (gemv_fx_ksb): y = raw K-slice partial sums [ksb][rows][N]; no epilogue operands
   int dbg = 0;                                    // ablation mask for tools/gemv_probe.hip only
 };
+int gemv_fx_ksb(int N, int K);
+int gemv_fx_combine(const float* slab, int ksb, int rows, int N, const float* bias, const float* res, float* y, hipStream_t stream);
 void gemv_fx_plan(int N, int K, int rows, int* ntw, int* kw);
 int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t stream);
 

@@ -62,6 +62,7 @@ struct GemvFXP {
   const float* res;         // residual, same layout as y, may alias y
   float* y; int y_frag; int ldy;   // y_frag: fragment images with kc16 = N/16 (N % 16 == 0), else row-major [rows][ldy]
   int rows, N, K, kc16, ntiles, kw, cps, act;
+  int ksb;                  // > 1: K also split across gridDim.y workgroups; y = raw partial sums [ksb][rows][N] (row-major)
   int dbg;
 };
 
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nt0 = blockIdx.x * NTW;
-  const int c0 = wave * p.cps;
+  const int c0 = (blockIdx.y * p.kw + wave) * p.cps;
   const int nch = max(0, min(p.cps, p.kc16 - c0));
   const bool ln = p.colsum != nullptr;
 
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
   float e_bias = 0.f, e_u = 0.f, e_res = 0.f;
   if (e_ok) {
     e_addr = p.y_frag ? frag_index(e_row, e_col, p.N >> 4) : (size_t)e_row * p.ldy + e_col;
+    if (p.ksb > 1) e_addr = ((size_t)blockIdx.y * p.rows + e_row) * p.N + e_col;
     if (p.bias) e_bias = p.bias[e_col];
     if (ln) e_u = p.colsum[e_col];
     if (p.res) e_res = p.res[e_addr];
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
     if (tid < MT * 16) {     // Chan / Welford pairwise update over the K-slices, fixed order
       float n = 0.f, mean = 0.f, m2 = 0.f;
       for (int w = 0; w < p.kw; ++w) {
-        const float nw = 16.0f * max(0, min(p.cps, p.kc16 - w * p.cps));
+        const float nw = 16.0f * max(0, min(p.cps, p.kc16 - w * p.cps));      // (folded LayerNorm implies ksb == 1)
         if (nw == 0.f) continue;
         const float mw = wstat[(w * MT * 16 + tid) * 2], qw = wstat[(w * MT * 16 + tid) * 2 + 1];
         const float dlt = mw - mean, nn = n + nw;
@@ -238,6 +240,42 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
   }
 }
 
+// Narrow layers (N = d: 80 column tiles) with a long K (mlp.c_proj: 26 MB) cannot reach HBM speed from 80 workgroups:
+// a CU sustains ~11 B/clk from HBM (tools/l2_probe.hip), so all 256 have to stream.  Their K is split across `ksb`
+// workgroups per column tile; the partial sums go to a [ksb][rows][N] slab and gemv_fx_combine adds them in a fixed order
+// (bitwise reproducible) together with bias and residual.
+int gemv_fx_ksb(int N, int K) {
+  static const int forced = getenv("IDXTTS_FX_KSB") ? atoi(getenv("IDXTTS_FX_KSB")) : 0;
+  if (forced > 0) return (cdiv(K, 16) / forced >= 16) ? forced : 1;
+  const int ntiles = cdiv(N, 16), kc16 = cdiv(K, 16);
+  return (ntiles <= 128 && kc16 >= 256) ? 4 : 1;
+}
+
+__global__ __launch_bounds__(256) void gemv_fx_combine_kernel(const float* __restrict__ slab, int ksb, int rows, int N, const float* __restrict__ bias,
+                                                              const float* res, float* y) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * N) return;
+  const int row = idx / N, col = idx - row * N;
+  float t[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) t[s] = s < ksb ? slab[((size_t)s * rows + row) * N + col] : 0.f;
+  const size_t o = frag_index(row, col, N >> 4);
+  float v = res ? res[o] : 0.f;
+  if (bias) v += bias[col];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) v += t[s];
+  y[o] = v;
+}
+
+// y (fragment images over N) = res + bias + sum_s slab[s]
+int gemv_fx_combine(const float* slab, int ksb, int rows, int N, const float* bias, const float* res, float* y, hipStream_t stream) {
+  IDX_CHECK(slab && y && ksb >= 1 && ksb <= 8 && N % 16 == 0, "combine arguments");
+  ProfScope prof(PROF_ROWS_NORM, stream, 0.0, 4.0 * rows * (double)N * (ksb + 2));
+  hipLaunchKernelGGL(gemv_fx_combine_kernel, dim3(cdiv(rows * N, 256)), dim3(256), 0, stream, slab, ksb, rows, N, bias, res, y);
+  IDX_LAUNCH_CHECK();
+  return 0;
+}
+
 void gemv_fx_plan(int N, int K, int rows, int* ntw, int* kw) {
   const int kc16 = cdiv(K, 16), ntiles = cdiv(N, 16), MT = cdiv(rows, 16);
   int k = 16;
@@ -261,14 +299,16 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
   p.rows = a.rows; p.N = w.N; p.K = w.K; p.kc16 = cdiv(w.K, 16); p.ntiles = cdiv(w.N, 16);
   int ntw = 1;
   gemv_fx_plan(w.N, w.K, a.rows, &ntw, &p.kw);
-  p.cps = cdiv(p.kc16, p.kw);
+  p.ksb = a.ksb > 1 ? a.ksb : 1;
+  if (p.ksb > 1) IDX_CHECK(!a.colsum && !a.bias && !a.res && a.act == 0 && !a.y_frag, "a K-split launch writes raw partial sums");
+  p.cps = cdiv(p.kc16, p.kw * p.ksb);
   p.act = a.act; p.dbg = a.dbg;
   const int MT = cdiv(a.rows, 16);
   const int nacc = MT * ntw;
   const int threads = std::max(64 * p.kw, 256 * nacc);      // one epilogue thread per output element of the workgroup
   IDX_CHECK(threads <= 1024, "workgroup size");
   const size_t lds = (size_t)(p.kw * nacc * 256 + p.kw * MT * 32 + MT * 32) * sizeof(float);
-  dim3 grid(cdiv(p.ntiles, ntw));
+  dim3 grid(cdiv(p.ntiles, ntw), p.ksb);
   const double flops = 2.0 * a.rows * (double)w.N * w.K;
   const double bytes = 4.0 * ((double)w.N * w.K + (double)a.rows * w.N * (a.res ? 2.0 : 1.0) + (double)a.rows * w.K);
   ProfScope prof(PROF_GEMV16, stream, flops, bytes);

@@ -32,7 +32,7 @@ struct GPTModel : ModelBase {
     float *x, *h, *qkv, *att, *ff;            // [B*S][..] prefill / latent activations
     float *kcache, *vcache; int Smax;         // [L][B][H][Smax][64] each
     float *xd, *hd, *attd, *ffd;              // decode residual / final-normed / attention output / mlp hidden: A-fragment images
-    float *qkvd, *logits;                     // [B][3d], [B][V] row-major
+    float *qkvd, *logits, *slab;              // [B][3d], [B][V] row-major; [<=8][B][d] K-split partial sums of mlp.c_proj
     size_t frag_off, frag_bytes;              // the fragment-image region (zeroed once per generate: padding rows stay 0)
     unsigned char* seen; int *finished, *cur_tok, *kstart;
     DecodeState* state;

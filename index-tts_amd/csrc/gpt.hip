@@ -170,6 +170,7 @@ GPTModel::Buffers GPTModel::carve(void* ws, int B, int S, int max_new) const {
   b.ffd = c.take<float>(frag_image_floats(B, 4 * d));
   b.frag_bytes = c.off - b.frag_off;
   b.qkvd = c.take<float>((size_t)B * 3 * d);
+  b.slab = c.take<float>((size_t)8 * B * d);
   b.logits = c.take<float>((size_t)B * V);
   b.seen = c.take<unsigned char>((size_t)B * V);
   b.finished = c.take<int>(B);
@@ -263,8 +264,16 @@ int GPTModel::decode_step(const Buffers& w, int B, float penalty, long long* cod
     fa.xf = w.xd; fa.rows = B; fa.colsum = L.fc_u; fa.bias = L.fc_c; fa.act = 1; fa.y = w.ffd; fa.y_frag = 1;
     if (gemv_fx_forward(L.fc_g, fa, st)) return 1;
     GemvFXArgs fb;      // x += mlp.c_proj(ff) + b
-    fb.xf = w.ffd; fb.rows = B; fb.bias = L.fc2_l.bias; fb.res = w.xd; fb.y = w.xd; fb.y_frag = 1;
-    if (gemv_fx_forward(L.fc2_g, fb, st)) return 1;
+    fb.xf = w.ffd; fb.rows = B;
+    const int ksb = gemv_fx_ksb(L.fc2_g.N, L.fc2_g.K);
+    if (ksb > 1) {      // K split across workgroups (all 256 CUs stream), partial sums combined in a fixed order
+      fb.ksb = ksb; fb.y = w.slab; fb.ldy = d;
+      if (gemv_fx_forward(L.fc2_g, fb, st)) return 1;
+      if (gemv_fx_combine(w.slab, ksb, B, d, L.fc2_l.bias, w.xd, w.xd, st)) return 1;
+    } else {
+      fb.bias = L.fc2_l.bias; fb.res = w.xd; fb.y = w.xd; fb.y_frag = 1;
+      if (gemv_fx_forward(L.fc2_g, fb, st)) return 1;
+    }
   }
   if (head_and_sample(w, B, w.xd, d, true, penalty, codes, codes_ld, logits_base, st)) return 1;
   return advance_state(w.state, st);
