@@ -248,7 +248,7 @@ int gemv_fx_ksb(int N, int K) {
   static const int forced = getenv("IDXTTS_FX_KSB") ? atoi(getenv("IDXTTS_FX_KSB")) : 0;
   if (forced > 0) return (cdiv(K, 16) / forced >= 16) ? forced : 1;
   const int ntiles = cdiv(N, 16), kc16 = cdiv(K, 16);
-  return (ntiles <= 128 && kc16 >= 256) ? 4 : 1;
+  return (ntiles <= 128 && kc16 >= 64) ? 4 : 1;
 }
 
 __global__ __launch_bounds__(256) void gemv_fx_combine_kernel(const float* __restrict__ slab, int ksb, int rows, int N, const float* __restrict__ bias,

@@ -256,3 +256,22 @@ def test_greedy_batch_above_16_rows_vs_oracle(device):
     codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=12, repetition_penalty=10.0)
     ref = og.generate_greedy(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, 12, 10.0)
     assert np.array_equal(codes.cpu().numpy(), ref.numpy())
+
+
+def test_greedy_wide_mlp_k_split_vs_oracle(device):
+    """model_dim 256: mlp.c_proj has K = 1024, the shape class whose decode GEMV is split across workgroups
+    (partial-sum slab + fixed-order combine, gemv_fx_ksb); codes must still equal the oracle's."""
+    from indextts_amd.gpt import UnifiedVoice
+    from oracle import gpt as og
+    cfg = GPTConfig(model_dim=256, heads=4, layers=2, number_text_tokens=300, number_mel_codes=258, start_mel_token=256,
+                    stop_mel_token=257, max_mel_tokens=120, max_text_tokens=60, cond_latents=6)
+    w = weights.synth_gpt_weights(cfg, tag="t/gpt/wide")
+    uv = UnifiedVoice(w, cfg, device=device)
+    tw = {k: torch.from_numpy(v) for k, v in w.items()}
+    B, L = 5, 9
+    lat = torch.from_numpy(synth.uniform("t/gpt/wide/lat", (B, cfg.cond_latents, cfg.model_dim), 0.5))
+    emo = torch.from_numpy(synth.uniform("t/gpt/wide/emo", (B, cfg.model_dim), 0.3))
+    text = torch.from_numpy(synth.integers("t/gpt/wide/text", (B, L), 2, cfg.number_text_tokens))
+    codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=14, repetition_penalty=10.0)
+    ref = og.generate_greedy(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, 14, 10.0)
+    assert np.array_equal(codes.cpu().numpy(), ref.numpy())
