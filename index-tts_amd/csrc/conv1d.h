@@ -14,6 +14,7 @@ enum ConvPadMode { PAD_ZERO = 0, PAD_REFLECT = 1 };
 
 struct ConvWeights {           // packed, device-resident
   const float* wp = nullptr;   // [ceil(M/32)][nchunk][K][g2][h2][i32][4]
+  const void* wp16 = nullptr;  // optional split-bf16 images [ceil(M/32)][nchunk][K][hl][g2][i32][8] (conv1d_bf16x3.hip)
   const float* bias = nullptr; // [Cout_real] or null
   int M = 0;                   // GEMM rows (= Cout, or Cout*u for a transposed conv)
   int Cin = 0;
@@ -46,5 +47,8 @@ struct ConvArgs {
 };
 
 int conv1d_forward(const ConvWeights& w, const ConvArgs& a, hipStream_t stream);
+// split-bf16 path for M > 96 rows (taken by conv1d_forward when the GEMM mode is GEMM_BF16X3 and w.wp16 is set)
+void pack_conv_bf16x3(void* dst, const float* packed_f32, size_t n_subtiles);
+int conv1d_bf16x3_forward(const ConvWeights& w, const ConvArgs& a, hipStream_t stream);
 
 }  // namespace idxtts

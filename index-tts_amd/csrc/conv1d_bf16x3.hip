@@ -1,0 +1,283 @@
+// Split-bf16 variant of the channels-first implicit-GEMM Conv1d (conv1d.hip) for the wide vocoder layers (M > 96 rows:
+// conv_pre, the first four upsamplers and AMP-block stages of BigVGAN, bigvgan.py:362-379): same tiling, same epilogue,
+// but the contraction runs on v_mfma_f32_32x32x16_bf16 with every fp32 operand written as hi + lo (bf16 each) and three
+// MFMAs per product (hi*hi + hi*lo + lo*hi, fp32 accumulation; relative product error ~2^-16).  12 bf16 MFMAs (384
+// cycles) per (16-channel chunk, tap) and 64 x 64 wave tile instead of 32 f32 MFMAs (2048 cycles).
+//
+// What changes against the fp32 kernel is the x tile: the bf16 MFMA wants the 8 input channels of a k-slot group packed
+// in ONE lane, so the tile is stored time-major in LDS, [t][16 ci] bf16 (32-byte rows, hi and lo planes).  The loader
+// assigns a lane 4 adjacent channels x strided time steps (coalesced 4-byte global loads along t), packs the 4 channels
+// to 8 bytes and writes row t: the 64 lanes of a store cover 16 complete rows = 512 contiguous bytes (conflict-free).
+// A tap is a shifted ROW, so every dilation / tap offset is a plain ds_read_b128 (16-byte slot swizzled by row bit 3:
+// conflict-free).  Weights are permuted once at load from the fp32 pack into per-sub-tile [hl][g2][i32][8] bf16 images
+// (same 2 KiB per sub-tile and tap).
+#include <cstring>
+
+#include "conv1d.h"
+#include "prof.h"
+
+namespace idxtts {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+static inline uint16_t f2bf_c(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf2f_c(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+
+// fp32 pack [.. sub-tile ..][g2][h2][i32][4] (ci = 8g + 4h + e)  ->  [.. sub-tile ..][hl][g2][i32][8] bf16 (k-slot 4h + e)
+void pack_conv_bf16x3(void* dst, const float* packed_f32, size_t n_subtiles) {
+  uint16_t* o = static_cast<uint16_t*>(dst);
+  for (size_t s = 0; s < n_subtiles; ++s) {
+    const float* src = packed_f32 + s * CONV_SUB;
+    uint16_t* hi = o + s * 1024;      // 2 planes x 512 bf16
+    uint16_t* lo = hi + 512;
+    for (int g = 0; g < 2; ++g)
+      for (int h = 0; h < 2; ++h)
+        for (int i = 0; i < 32; ++i)
+          for (int e = 0; e < 4; ++e) {
+            const float x = src[((g * 2 + h) * 32 + i) * 4 + e];
+            const uint16_t xh = f2bf_c(x);
+            const int d = (g * 32 + i) * 8 + 4 * h + e;
+            hi[d] = xh;
+            lo[d] = f2bf_c(x - bf2f_c(xh));
+          }
+  }
+}
+
+struct ConvKP16 {
+  const float* x;
+  const void* wp16;
+  const float* bias;
+  const float* res;
+  float* y;
+  int Cin, M, T;
+  int K, dil, pad_left, pad_mode;
+  int nchunk, mt32;
+  int ups_log2;
+  int xt;                 // x tile rows (BN + (K-1)*dil)
+  int ntiles_row, ntiles, nt8;
+  float scale;
+  int accum;
+};
+
+constexpr int XROW_B = 32;            // bytes per LDS x row (16 ci bf16)
+constexpr int XT_MAX = 128 + CONV_MAX_HALO;
+
+template <int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(const ConvKP16 p) {
+  constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
+  constexpr int NSUB = TM * WGM;
+  constexpr int NXJ = (BN + CONV_MAX_HALO + 63) / 64;    // time steps per lane in the x loader
+  constexpr int NW4 = NSUB * 128;                        // 16-byte units per weight tile (2 KiB per sub-tile)
+  constexpr int NWL = (NW4 + 255) / 256;
+  constexpr int XPLANE = XT_MAX * XROW_B;                // bytes of one x plane
+  static_assert(WGM * WGN == 4 && BN <= 128, "4 waves, <= 128 columns");
+
+  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  char* Ws = smem16;                           // [2][NSUB][hl][g2][i32][8] bf16
+  char* Xs = smem16 + 2 * NSUB * 2048;         // [2][hl][XT_MAX][16 ci] bf16
+
+  const int L = blockIdx.x, xcd = L & 7, q = L >> 3;
+  const int m_blk = q / p.nt8;
+  const int n_idx = (q - m_blk * p.nt8) * 8 + xcd;
+  if (n_idx >= p.ntiles) return;
+  const int b = n_idx / p.ntiles_row;
+  const int t0 = (n_idx - b * p.ntiles_row) * BN;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int h = lane >> 5, j = lane & 31;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int T = p.T, XT = p.xt;
+  const float* xrow_base = p.x + (size_t)b * p.Cin * T;
+
+  // x loader role: channels 4cg..4cg+3 of the chunk, tile rows tq + 64*jj
+  const int cg = tid & 3, tq = tid >> 2;
+  float xr[NXJ][4];
+  f32x4 wr[NWL];
+
+  auto load_x = [&](int chunk) {
+#pragma unroll
+    for (int jj = 0; jj < NXJ; ++jj) {
+      const int c = tq + 64 * jj;
+      int t = t0 - p.pad_left + c;
+      if (p.pad_mode == PAD_REFLECT) {
+        t = t < 0 ? -t : t;
+        t = t >= T ? 2 * (T - 1) - t : t;
+      }
+      const bool tok = c < XT && t >= 0 && t < T;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ci = chunk * CONV_KC + cg * 4 + e;
+        xr[jj][e] = (tok && ci < p.Cin) ? xrow_base[(size_t)ci * T + t] : 0.0f;
+      }
+    }
+  };
+  auto store_x = [&](int buf) {
+    char* dst = Xs + buf * 2 * XPLANE;
+#pragma unroll
+    for (int jj = 0; jj < NXJ; ++jj) {
+      const int c = tq + 64 * jj;
+      if (c < XT) {
+        const f32x4 v = {xr[jj][0], xr[jj][1], xr[jj][2], xr[jj][3]};
+        const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+        const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+        const int off = c * XROW_B + (((cg >> 1) ^ ((c >> 3) & 1)) << 4) + ((cg & 1) << 3);
+        *reinterpret_cast<bf16x4*>(dst + off) = hi;
+        *reinterpret_cast<bf16x4*>(dst + XPLANE + off) = lo;
+      }
+    }
+  };
+  auto load_w = [&](int chunk, int tap) {
+#pragma unroll
+    for (int l = 0; l < NWL; ++l) {
+      const int idx = tid + l * 256;
+      const int sub = idx >> 7, off = idx & 127;
+      const int mt = m_blk * NSUB + sub;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < NW4 && mt < p.mt32)
+        v = *reinterpret_cast<const f32x4*>(static_cast<const char*>(p.wp16) + (((size_t)mt * p.nchunk + chunk) * p.K + tap) * 2048 + off * 16);
+      wr[l] = v;
+    }
+  };
+  auto store_w = [&](int buf) {
+    char* dst = Ws + buf * NSUB * 2048;
+#pragma unroll
+    for (int l = 0; l < NWL; ++l) {
+      const int idx = tid + l * 256;
+      if (idx < NW4) *reinterpret_cast<f32x4*>(dst + idx * 16) = wr[l];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+  load_x(0);
+  load_w(0, 0);
+  store_x(0);
+  store_w(0);
+  __syncthreads();
+
+  const int total = p.nchunk * p.K;
+  int chunk = 0, tap = 0;
+  for (int it = 0; it < total; ++it) {
+    int nchunk_i = chunk, ntap = tap + 1;
+    if (ntap == p.K) { ntap = 0; nchunk_i = chunk + 1; }
+    const bool has_next = it + 1 < total;
+    const bool next_x = has_next && ntap == 0;
+    if (has_next) load_w(nchunk_i, ntap);
+    if (next_x) load_x(nchunk_i);
+
+    {
+      const char* xb = Xs + (chunk & 1) * 2 * XPLANE;
+      const char* wb = Ws + (it & 1) * NSUB * 2048;
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt) {
+        const char* wsub = wb + (wm * TM + mt) * 2048 + (h * 32 + j) * 16;
+        ah[mt] = *reinterpret_cast<const bf16x8*>(wsub);
+        al[mt] = *reinterpret_cast<const bf16x8*>(wsub + 1024);
+      }
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) {
+        const int row = (wn * TN + nt) * 32 + j + tap * p.dil;
+        const int off = row * XROW_B + ((h ^ ((row >> 3) & 1)) << 4);
+        bh[nt] = *reinterpret_cast<const bf16x8*>(xb + off);
+        bl[nt] = *reinterpret_cast<const bf16x8*>(xb + XPLANE + off);
+      }
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+
+    if (has_next) store_w((it + 1) & 1);
+    if (next_x) store_x(nchunk_i & 1);
+    __syncthreads();
+    chunk = nchunk_i;
+    tap = ntap;
+  }
+
+  // ---- epilogue: bias, residual, scale, (accumulate), store (as conv1d.hip) ----
+  const int u_log2 = p.ups_log2, u_mask = (1 << u_log2) - 1;
+  const int Cout = p.M >> u_log2;
+  const size_t Tout = (size_t)T << u_log2;
+#pragma unroll
+  for (int mt = 0; mt < TM; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m_blk * BM + (wm * TM + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m >= p.M) continue;
+      const int co = m >> u_log2, ph = m & u_mask;
+      const float bias = p.bias ? p.bias[co] : 0.0f;
+      const size_t rowoff = ((size_t)b * Cout + co) * Tout + ph;
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) {
+        const int n = t0 + (wn * TN + nt) * 32 + j;
+        if (n >= T) continue;
+        const size_t idx = rowoff + ((size_t)n << u_log2);
+        float v = acc[mt][nt][r] + bias;
+        if (p.res) v += p.res[idx];
+        v *= p.scale;
+        if (p.accum) v += p.y[idx];
+        p.y[idx] = v;
+      }
+    }
+  }
+}
+
+int conv1d_bf16x3_forward(const ConvWeights& w, const ConvArgs& a, hipStream_t stream) {
+  constexpr int TM = 2, TN = 2, WGM = 2, WGN = 2;
+  constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, NSUB = TM * WGM;
+  IDX_CHECK(w.wp16 && a.x && a.y, "null pointer");
+  ConvKP16 p;
+  p.x = a.x; p.wp16 = w.wp16; p.bias = w.bias; p.res = a.res; p.y = a.y;
+  p.Cin = w.Cin; p.M = w.M; p.T = a.T;
+  p.K = w.K; p.dil = a.dil; p.pad_left = a.pad_left; p.pad_mode = a.pad_mode;
+  p.nchunk = w.nchunk; p.mt32 = cdiv(w.M, CONV_MT);
+  int ul = 0;
+  while ((1 << ul) < w.ups) ++ul;
+  IDX_CHECK((1 << ul) == w.ups, "transposed-conv stride must be a power of two");
+  p.ups_log2 = ul;
+  const int halo = (w.K - 1) * a.dil;
+  IDX_CHECK(halo <= CONV_MAX_HALO, "(K-1)*dil exceeds CONV_MAX_HALO");
+  p.xt = BN + halo;
+  p.ntiles_row = cdiv(a.T, BN);
+  p.ntiles = p.ntiles_row * a.B;
+  p.nt8 = cdiv(p.ntiles, 8);
+  p.scale = a.scale; p.accum = a.accum;
+  const int mblocks = cdiv(w.M, BM);
+  const size_t lds = (size_t)2 * NSUB * 2048 + (size_t)2 * 2 * XT_MAX * XROW_B;
+  const int64_t grid = (int64_t)8 * mblocks * p.nt8;
+  IDX_CHECK(grid > 0 && grid < (1ll << 31), "grid size");
+  const double cout = (double)(w.M / w.ups), tout = (double)a.T * w.ups * a.B;
+  const double taps = w.ups > 1 ? 2.0 : (double)w.K;
+  const double flops = 2.0 * cout * w.Cin * taps * tout;
+  const double bytes = 4.0 * ((double)a.B * w.Cin * a.T + cout * tout * (1.0 + (a.res ? 1.0 : 0.0) + (a.accum ? 1.0 : 0.0)) +
+                              cout * w.Cin * (w.ups > 1 ? 2.0 * w.ups : (double)w.K));
+  ProfScope prof(PROF_CONV_128x128, stream, flops, bytes);
+  hipLaunchKernelGGL((conv1d_bf16x3_kernel<TM, TN, WGM, WGN>), dim3((unsigned)grid), dim3(256), lds, stream, p);
+  IDX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace idxtts
