@@ -98,7 +98,7 @@ static int make_conv(std::map<std::string, HostTensor>& t, DeviceArena& arena, c
   float* d = nullptr;
   if (arena.upload(packed.data(), packed.size(), &d)) return 1;
   cw.wp = d;
-  if (cw.M > 96) {      // split-bf16 images for the wide layers (conv1d_bf16x3.hip); same size as the fp32 pack
+  {                     // split-bf16 images (conv1d_bf16x3.hip); same size as the fp32 pack
     std::vector<float> p16(packed.size());      // hi + lo bf16 = 4 bytes per weight, as the fp32 pack
     pack_conv_bf16x3(p16.data(), packed.data(), packed.size() / CONV_SUB);
     if (arena.upload(p16.data(), p16.size(), &d)) return 1;

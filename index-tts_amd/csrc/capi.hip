@@ -92,7 +92,7 @@ int idxtts_conv1d_create(const float* weight, const float* bias, int Cout, int C
   float* d = nullptr;
   if (c->arena.upload(packed.data(), packed.size(), &d)) return 1;
   c->w.wp = d;
-  if (c->w.M > 96) {
+  {
     std::vector<float> p16(packed.size());      // hi + lo bf16 = 4 bytes per weight, as the fp32 pack
     pack_conv_bf16x3(p16.data(), packed.data(), packed.size() / CONV_SUB);
     if (c->arena.upload(p16.data(), p16.size(), &d)) return 1;

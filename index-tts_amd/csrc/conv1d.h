@@ -47,7 +47,7 @@ struct ConvArgs {
 };
 
 int conv1d_forward(const ConvWeights& w, const ConvArgs& a, hipStream_t stream);
-// split-bf16 path for M > 96 rows (taken by conv1d_forward when the GEMM mode is GEMM_BF16X3 and w.wp16 is set)
+// split-bf16 path (taken by conv1d_forward when the GEMM mode is GEMM_BF16X3 and w.wp16 is set)
 void pack_conv_bf16x3(void* dst, const float* packed_f32, size_t n_subtiles);
 int conv1d_bf16x3_forward(const ConvWeights& w, const ConvArgs& a, hipStream_t stream);
 

@@ -302,7 +302,7 @@ int conv1d_forward(const ConvWeights& w, const ConvArgs& a, hipStream_t stream) 
   IDX_CHECK(w.wp && a.x && a.y, "null pointer");
   IDX_CHECK(a.B > 0 && a.T > 0, "empty shape");
   if (a.pad_mode == PAD_REFLECT) IDX_CHECK(a.T > (w.K - 1) * a.dil, "reflect pad needs T > halo");
-  if (w.M > 96 && w.wp16 && get_gemm_mode() == GEMM_BF16X3) return conv1d_bf16x3_forward(w, a, stream);
+  if (w.wp16 && get_gemm_mode() == GEMM_BF16X3) return conv1d_bf16x3_forward(w, a, stream);
   if (w.M > 96) return launch_conv<2, 2, 2, 2, PROF_CONV_128x128>(w, a, stream);   // 128 x 128
   if (w.M > 64) return launch_conv<3, 2, 1, 4, PROF_CONV_96x256>(w, a, stream);   //  96 x 256
   if (w.M > 32) return launch_conv<2, 2, 1, 4, PROF_CONV_64x256>(w, a, stream);   //  64 x 256

@@ -72,7 +72,6 @@ struct ConvKP16 {
 };
 
 constexpr int XROW_B = 32;            // bytes per LDS x row (16 ci bf16)
-constexpr int XT_MAX = 128 + CONV_MAX_HALO;
 
 template <int TM, int TN, int WGM, int WGN>
 __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(const ConvKP16 p) {
@@ -81,8 +80,9 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(const ConvKP16 p) {
   constexpr int NXJ = (BN + CONV_MAX_HALO + 63) / 64;    // time steps per lane in the x loader
   constexpr int NW4 = NSUB * 128;                        // 16-byte units per weight tile (2 KiB per sub-tile)
   constexpr int NWL = (NW4 + 255) / 256;
+  constexpr int XT_MAX = BN + CONV_MAX_HALO;
   constexpr int XPLANE = XT_MAX * XROW_B;                // bytes of one x plane
-  static_assert(WGM * WGN == 4 && BN <= 128, "4 waves, <= 128 columns");
+  static_assert(WGM * WGN == 4, "4 waves");
 
   extern __shared__ __attribute__((aligned(16))) char smem16[];
   char* Ws = smem16;                           // [2][NSUB][hl][g2][i32][8] bf16
@@ -245,9 +245,10 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(const ConvKP16 p) {
   }
 }
 
-int conv1d_bf16x3_forward(const ConvWeights& w, const ConvArgs& a, hipStream_t stream) {
-  constexpr int TM = 2, TN = 2, WGM = 2, WGN = 2;
+template <int TM, int TN, int WGM, int WGN, int CAT>
+static int launch_conv16(const ConvWeights& w, const ConvArgs& a, hipStream_t stream) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, NSUB = TM * WGM;
+  constexpr int XT_MAX = BN + CONV_MAX_HALO;
   IDX_CHECK(w.wp16 && a.x && a.y, "null pointer");
   ConvKP16 p;
   p.x = a.x; p.wp16 = w.wp16; p.bias = w.bias; p.res = a.res; p.y = a.y;
@@ -269,15 +270,29 @@ int conv1d_bf16x3_forward(const ConvWeights& w, const ConvArgs& a, hipStream_t s
   const size_t lds = (size_t)2 * NSUB * 2048 + (size_t)2 * 2 * XT_MAX * XROW_B;
   const int64_t grid = (int64_t)8 * mblocks * p.nt8;
   IDX_CHECK(grid > 0 && grid < (1ll << 31), "grid size");
+  auto kern = conv1d_bf16x3_kernel<TM, TN, WGM, WGN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
   const double cout = (double)(w.M / w.ups), tout = (double)a.T * w.ups * a.B;
   const double taps = w.ups > 1 ? 2.0 : (double)w.K;
   const double flops = 2.0 * cout * w.Cin * taps * tout;
   const double bytes = 4.0 * ((double)a.B * w.Cin * a.T + cout * tout * (1.0 + (a.res ? 1.0 : 0.0) + (a.accum ? 1.0 : 0.0)) +
                               cout * w.Cin * (w.ups > 1 ? 2.0 * w.ups : (double)w.K));
-  ProfScope prof(PROF_CONV_128x128, stream, flops, bytes);
-  hipLaunchKernelGGL((conv1d_bf16x3_kernel<TM, TN, WGM, WGN>), dim3((unsigned)grid), dim3(256), lds, stream, p);
+  ProfScope prof(CAT, stream, flops, bytes);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p);
   IDX_LAUNCH_CHECK();
   return 0;
+}
+
+// same tile configurations as conv1d_forward
+int conv1d_bf16x3_forward(const ConvWeights& w, const ConvArgs& a, hipStream_t stream) {
+  if (w.M > 96) return launch_conv16<2, 2, 2, 2, PROF_CONV_128x128>(w, a, stream);   // 128 x 128
+  if (w.M > 64) return launch_conv16<3, 2, 1, 4, PROF_CONV_96x256>(w, a, stream);   //  96 x 256
+  if (w.M > 32) return launch_conv16<2, 2, 1, 4, PROF_CONV_64x256>(w, a, stream);   //  64 x 256
+  return launch_conv16<1, 4, 1, 4, PROF_CONV_32x512>(w, a, stream);                 //  32 x 512
 }
 
 }  // namespace idxtts
