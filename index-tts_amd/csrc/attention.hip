@@ -194,10 +194,7 @@ constexpr int KB16 = 144;          // K row bytes: 64 bf16 + 8 pad
 constexpr int VB16 = 192;          // V row bytes: 64 bf16 + 32 pad
 constexpr int ABUF = 2 * 32 * KB16 + 2 * 32 * VB16;     // hi/lo K, hi/lo V of one 32-key tile: 21504 B
 
-__device__ __forceinline__ void split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
-  hi = __builtin_convertvector(v, bf16x4);
-  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
-}
+__device__ __forceinline__ void split4(const f32x4 v, bf16x4& hi, bf16x4& lo) { split_bf16_x4(v, hi, lo); }
 
 __global__ __launch_bounds__(256) void flash_attn_bf16x3_kernel(const AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * ABUF];

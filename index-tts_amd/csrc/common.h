@@ -25,6 +25,24 @@ int fail(const char* file, int line, const std::string& msg);
 __host__ __device__ static inline size_t frag_index(int row, int k, int kc16) {
   return ((((size_t)(row >> 4) * kc16 + (k >> 4)) * 64 + ((k & 15) >> 2) * 16 + (row & 15)) << 2) + (k & 3);
 }
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 significant bits): the operand form of every split-bf16 kernel.
+// Four elements -> two packed 8-byte groups; 10 VALU instructions (2 v_cvt_pk_bf16_f32 per plane, packed subtract), where
+// the vector-convert idiom costs 16.
+typedef __bf16 idx_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_bf16_x4(const f32x4 v, idx_bf16x4& hi, idx_bf16x4& lo) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{v[0], v[1]}, b2));
+  const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{v[2], v[3]}, b2));
+  const f2 r0 = f2{v[0], v[1]} - f2{__builtin_bit_cast(float, h0 << 16), __builtin_bit_cast(float, h0 & 0xffff0000u)};
+  const f2 r1 = f2{v[2], v[3]} - f2{__builtin_bit_cast(float, h1 << 16), __builtin_bit_cast(float, h1 & 0xffff0000u)};
+  const unsigned l0 = __builtin_bit_cast(unsigned, __builtin_convertvector(r0, b2));
+  const unsigned l1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, b2));
+  hi = __builtin_bit_cast(idx_bf16x4, u2{h0, h1});
+  lo = __builtin_bit_cast(idx_bf16x4, u2{l0, l1});
+}
+
 // Split-bf16 GEMM operands (gemm_bf16x3_v2.hip): activation x[rows][K] fp32 as two bf16 planes (hi, lo = x - hi), each
 // [K/16][rows][16]: a 16-k chunk of all rows is one contiguous run.  Producers may write them directly.
 __host__ __device__ static inline size_t plane_index(int row, int k, int rows) { return ((size_t)(k >> 4) * rows + row) * 16 + (k & 15); }

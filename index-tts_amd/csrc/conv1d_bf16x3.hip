@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(const ConvKP16 p) {
       const int c = tq + 64 * jj;
       if (c < XT) {
         const f32x4 v = {xr[jj][0], xr[jj][1], xr[jj][2], xr[jj][3]};
-        const bf16x4 hi = __builtin_convertvector(v, bf16x4);
-        const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+        bf16x4 hi, lo;
+        split_bf16_x4(v, hi, lo);
         const int off = c * XROW_B + (((cg >> 1) ^ ((c >> 3) & 1)) << 4) + ((cg & 1) << 3);
         *reinterpret_cast<bf16x4*>(dst + off) = hi;
         *reinterpret_cast<bf16x4*>(dst + XPLANE + off) = lo;

@@ -73,9 +73,8 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     const int m = blockIdx.x * 64 + (threadIdx.x >> 4) + 16 * i;
     if (m >= M || k >= ((K + 15) & ~15)) continue;
     const f32x4 v = k < K ? *reinterpret_cast<const f32x4*>(x + (size_t)m * ldx + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const bf16x4 h = __builtin_convertvector(v, bf16x4);
-    const f32x4 back = __builtin_convertvector(h, f32x4);
-    const bf16x4 l = __builtin_convertvector(v - back, bf16x4);
+    bf16x4 h, l;
+    split_bf16_x4(v, h, l);
     const size_t o = ((size_t)(k >> 4) * M + m) * 16 + (k & 15);
     *reinterpret_cast<bf16x4*>(hi + o) = h;
     *reinterpret_cast<bf16x4*>(lo + o) = l;

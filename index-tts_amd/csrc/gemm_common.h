@@ -168,8 +168,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmKP& p, f32x16 (&acc)
         if (p.y) *reinterpret_cast<f32x4*>(dst) = v;
         if (p.y_hi) {       // n_out % 4 == 0: the four columns share a 16-k chunk
           typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-          const bf16x4_t hi = __builtin_convertvector(v, bf16x4_t);
-          const bf16x4_t lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4_t);
+          bf16x4_t hi, lo;
+          split_bf16_x4(v, hi, lo);
           const size_t o = plane_index(m, n_out, p.M);
           *reinterpret_cast<bf16x4_t*>(p.y_hi + o) = hi;
           *reinterpret_cast<bf16x4_t*>(p.y_lo + o) = lo;
