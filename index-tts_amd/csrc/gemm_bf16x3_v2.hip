@@ -87,16 +87,31 @@ struct GemmV2P {
   const __bf16* b_hi; const __bf16* b_lo;   // [K/16][npad][16]
   const __bf16* zeros;           // >= 32 bytes of zeros (rows outside M / outside the sequence)
   int a_rows, npad, nstages;
-  int dbg;       // ablation (tools/gemm_bench.py, IDXTTS_V2_DBG): 1 = every stage re-reads stage 0 (cache-hot operands), 2 = no MFMA
 };
-
-constexpr int V2_STAGE_BYTES = 4 * 256 * 32;     // A_hi, A_lo, B_hi, B_lo : [256 rows][32 B]
-constexpr int V2_NSTAGE = 4;
 
 #define GLDS16(gptr, lptr) \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-__global__ __launch_bounds__(512) void gemm_bf16x3_v2_kernel(const GemmV2P q) {
+template <int N> __device__ __forceinline__ void wait_vm_lgkm0();
+template <> __device__ __forceinline__ void wait_vm_lgkm0<0>() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vm_lgkm0<4>() { asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vm_lgkm0<6>() { asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vm_lgkm0<8>() { asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vm_lgkm0<12>() { asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vm_lgkm0<18>() { asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory"); }
+
+// Workgroup = 4 x WNW waves, each a 64 x 128 output tile (2 x 4 MFMA tiles): 256 x (128 WNW) per workgroup.
+//   WNW = 2: 512 threads, 32 KiB stages, 4-deep ring, one workgroup per CU;
+//   WNW = 1: 256 threads, 24 KiB stages, 3-deep ring, TWO workgroups per CU -- the waves that share a SIMD then belong to
+//            different workgroups with independent barriers, so one multiplies while the other waits / issues DMA.
+template <int WNW, int NSTAGE>
+__global__ __launch_bounds__(256 * WNW) void gemm_bf16x3_v2_kernel(const GemmV2P q) {
+  constexpr int NWV = 4 * WNW;                 // waves
+  constexpr int BN = 128 * WNW;
+  constexpr int A_PLANE = 256 * 32, B_PLANE = BN * 32;
+  constexpr int STAGE_BYTES = 2 * A_PLANE + 2 * B_PLANE;
+  constexpr int ARB = 8 / NWV, BRB = (BN / 32) / NWV;      // 32-row blocks of A / B a wave copies per plane and stage
+  constexpr int PPW = 2 * (ARB + BRB);                     // DMA instructions per wave and stage
   const GemmKP& p = q.g;
   extern __shared__ __attribute__((aligned(1024))) char smv2[];
 
@@ -108,55 +123,51 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v2_kernel(const GemmV2P q) {
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int h = lane >> 5, j = lane & 31;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WNW, wn = wave % WNW;
 
-  // ---- DMA role of this lane: tile row 32*wave + (lane >> 1), LDS unit lane & 1, source unit swizzled ----
-  const int drow = 32 * wave + (lane >> 1);
-  const int dunit = (lane & 1) ^ ((drow >> 3) & 1);
-  const int am = bm * 256 + drow;
-  int seq_base = 0, seq_t = 0, seq_n = 0;
-  if (p.taps > 1) {
-    const int sb = am / p.seq_len;
-    seq_base = sb * p.seq_len;
-    seq_t = am - seq_base;
-    seq_n = (p.row_len && am < p.M) ? min(p.row_len[sb], p.seq_len) : p.seq_len;
-  }
-  const size_t b_off = ((size_t)bn * 256 + drow) * 16 + dunit * 8;
-  const size_t a_plain = (size_t)min(am, q.a_rows - 1) * 16 + dunit * 8;
-  const bool a_ok = am < p.M;
-
-  // source pointers and LDS base of this lane's four DMA pieces of a stage
-  struct Pieces { const __bf16 *ah, *al, *bh, *bl; char* base; };
-  auto prep = [&](int st_real) -> Pieces {
-    const int st = (q.dbg & 1) ? 0 : st_real;
-    Pieces pc;
-    pc.base = smv2 + (st_real & (V2_NSTAGE - 1)) * V2_STAGE_BYTES + wave * 1024;     // wave-uniform: its 32 rows of each plane
+  // ---- DMA role of this lane: row (lane >> 1) of the wave's 32-row blocks, LDS unit lane & 1, source unit swizzled ----
+  const int lrow = lane >> 1;
+  const int dunit = (lane & 1) ^ ((lrow >> 3) & 1);        // block bases are multiples of 32: row bit 3 = lrow bit 3
+  int a_m[ARB], seq_base[ARB], seq_t[ARB], seq_n[ARB];
+#pragma unroll
+  for (int r = 0; r < ARB; ++r) {
+    a_m[r] = bm * 256 + 32 * (wave * ARB + r) + lrow;
+    seq_base[r] = seq_t[r] = seq_n[r] = 0;
     if (p.taps > 1) {
-      const int k0 = st * 16;
-      const int tap = k0 / p.kc, ch = (k0 - tap * p.kc) >> 4;
-      int t = seq_t + tap * p.dil - p.pad_left;
-      if (p.pad_mode == 1) { t = t < 0 ? -t : t; t = t >= seq_n ? 2 * (seq_n - 1) - t : t; }
-      const bool ok = a_ok && t >= 0 && t < seq_n;
-      const size_t o = ((size_t)ch * q.a_rows + (seq_base + (ok ? t : 0))) * 16 + dunit * 8;
-      pc.ah = ok ? q.a_hi + o : q.zeros;
-      pc.al = ok ? q.a_lo + o : q.zeros;
-    } else {
-      const size_t o = (size_t)st * q.a_rows * 16 + a_plain;
-      pc.ah = a_ok ? q.a_hi + o : q.zeros;
-      pc.al = a_ok ? q.a_lo + o : q.zeros;
+      const int sb = a_m[r] / p.seq_len;
+      seq_base[r] = sb * p.seq_len;
+      seq_t[r] = a_m[r] - seq_base[r];
+      seq_n[r] = (p.row_len && a_m[r] < p.M) ? min(p.row_len[sb], p.seq_len) : p.seq_len;
     }
-    const size_t bo = (size_t)st * q.npad * 16 + b_off;
-    pc.bh = q.b_hi + bo;
-    pc.bl = q.b_lo + bo;
-    return pc;
-  };
-  auto issue = [&](int st_real) {
-    if (q.dbg & 8) return;
-    const Pieces pc = prep(st_real);
-    GLDS16(pc.ah, pc.base);
-    GLDS16(pc.al, pc.base + 8192);
-    GLDS16(pc.bh, pc.base + 16384);
-    GLDS16(pc.bl, pc.base + 24576);
+  }
+
+  // one DMA instruction: piece `pi` (0 .. PPW-1) of stage `st`: [A row blocks: hi, lo] then [B row blocks: hi, lo]
+  auto issue_piece = [&](int st, int pi) {
+    char* sbase = smv2 + (st % NSTAGE) * STAGE_BYTES;
+    if (pi < 2 * ARB) {
+      const int r = pi >> 1, lo = pi & 1;
+      const int blk = wave * ARB + r;
+      size_t o;
+      bool ok = a_m[r] < p.M;
+      if (p.taps > 1) {
+        const int k0 = st * 16;
+        const int tap = k0 / p.kc, ch = (k0 - tap * p.kc) >> 4;
+        int t = seq_t[r] + tap * p.dil - p.pad_left;
+        if (p.pad_mode == 1) { t = t < 0 ? -t : t; t = t >= seq_n[r] ? 2 * (seq_n[r] - 1) - t : t; }
+        ok = ok && t >= 0 && t < seq_n[r];
+        o = ((size_t)ch * q.a_rows + (seq_base[r] + (ok ? t : 0))) * 16 + dunit * 8;
+      } else {
+        o = ((size_t)st * q.a_rows + min(a_m[r], q.a_rows - 1)) * 16 + dunit * 8;
+      }
+      const __bf16* src = ok ? (lo ? q.a_lo : q.a_hi) + o : q.zeros;
+      GLDS16(src, sbase + lo * A_PLANE + blk * 1024);
+    } else {
+      const int pb = pi - 2 * ARB;
+      const int r = pb >> 1, lo = pb & 1;
+      const int blk = wave * BRB + r;
+      const size_t o = ((size_t)st * q.npad + (size_t)bn * BN + 32 * blk + lrow) * 16 + dunit * 8;
+      GLDS16((lo ? q.b_lo : q.b_hi) + o, sbase + 2 * A_PLANE + lo * B_PLANE + blk * 1024);
+    }
   };
 
   f32x16 acc[2][4];
@@ -169,8 +180,11 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v2_kernel(const GemmV2P q) {
 
   const int ns = q.nstages;
 #pragma unroll
-  for (int s = 0; s < V2_NSTAGE; ++s)
-    if (s < ns) issue(s);
+  for (int s = 0; s < NSTAGE; ++s)
+    if (s < ns) {
+#pragma unroll
+      for (int pi = 0; pi < PPW; ++pi) issue_piece(s, pi);
+    }
 
   // fragment read offsets (bytes inside a plane image): row * 32 + (h ^ (row >> 3 & 1)) * 16, row = tile row of lane j
   const int sw = (h ^ ((j >> 3) & 1)) * 16;
@@ -178,56 +192,62 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v2_kernel(const GemmV2P q) {
   const int b_offr = (wn * 128 + j) * 32 + sw;        // + t * 1024 per 32-column tile
 
   struct Frag { bf16x8 ah[2], al[2], bh[4], bl[4]; };
-  // stage s has landed for the whole workgroup: this wave's pieces by the counted wait (stages s+1.. may stay in
-  // flight), everyone's by the barrier; the lgkmcnt(0) in front retires this wave's fragment reads of stage s - 1, so
-  // after the barrier that ring slot may be overwritten
+  // stage s has landed for the whole workgroup: this wave's pieces by the counted wait (younger stages may stay in
+  // flight), everyone's by the barrier; the lgkmcnt(0) retires this wave's fragment reads of stage s - 1, so after the
+  // barrier that ring slot may be overwritten
   auto wait_stage = [&](int s) {
-    const int issued = min(ns - 1, max(V2_NSTAGE - 1, s + 2));
+    const int issued = min(ns - 1, max(NSTAGE - 1, s + NSTAGE - 2));
     const int pending = issued - s;
-    if (pending >= 3) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-    else if (pending == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    else if (pending == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (!(q.dbg & 16)) __builtin_amdgcn_s_barrier();
+    if (pending >= 3) wait_vm_lgkm0<3 * PPW>();
+    else if (pending == 2) wait_vm_lgkm0<2 * PPW>();
+    else if (pending == 1) wait_vm_lgkm0<PPW>();
+    else wait_vm_lgkm0<0>();
+    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
   auto load_frags = [&](Frag& f, int s) {
-    const char* st = smv2 + (s & (V2_NSTAGE - 1)) * V2_STAGE_BYTES;
+    const char* st = smv2 + (s % NSTAGE) * STAGE_BYTES;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       f.ah[t] = *reinterpret_cast<const bf16x8*>(st + a_off + t * 1024);
-      f.al[t] = *reinterpret_cast<const bf16x8*>(st + 8192 + a_off + t * 1024);
+      f.al[t] = *reinterpret_cast<const bf16x8*>(st + A_PLANE + a_off + t * 1024);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      f.bh[t] = *reinterpret_cast<const bf16x8*>(st + 16384 + b_offr + t * 1024);
-      f.bl[t] = *reinterpret_cast<const bf16x8*>(st + 24576 + b_offr + t * 1024);
+      f.bh[t] = *reinterpret_cast<const bf16x8*>(st + 2 * A_PLANE + b_offr + t * 1024);
+      f.bl[t] = *reinterpret_cast<const bf16x8*>(st + 2 * A_PLANE + B_PLANE + b_offr + t * 1024);
     }
   };
-  // 24 MFMAs of stage i; the DMA of stage i + 4 (ring slot of stage i, free since the last barrier) is issued piecewise
-  // in their shadow (an LDS-DMA instruction costs ~100-180 issue cycles on its own, next to nothing behind an MFMA)
+  // 24 MFMAs of stage i; the DMA of stage i + NSTAGE (ring slot of stage i, free since the last barrier) is issued
+  // piecewise in their shadow (an LDS-DMA instruction costs ~100-180 issue cycles on its own, little behind an MFMA)
   auto compute = [&](const Frag& f, int i) {
-    const bool more = (i + V2_NSTAGE < ns) && !(q.dbg & 8);
-    const Pieces pc = prep(more ? i + V2_NSTAGE : 0);
+    const bool more = i + NSTAGE < ns;
+    const int nst = i + NSTAGE;
+    constexpr int PQ = (PPW + 3) / 4;          // pieces issued after each of the four MFMA groups
+    auto dma = [&](int g) {
+#pragma unroll
+      for (int u = 0; u < PQ; ++u)
+        if (g * PQ + u < PPW) issue_piece(nst, g * PQ + u);
+    };
 #define V2_MFMA3(mt, nt)                                                                                         \
     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);             \
     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], f.bl[nt], acc[mt][nt], 0, 0, 0);             \
     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
     V2_MFMA3(0, 0) V2_MFMA3(0, 1)
     __builtin_amdgcn_sched_barrier(0);
-    if (more) GLDS16(pc.ah, pc.base);
+    if (more) dma(0);
     __builtin_amdgcn_sched_barrier(0);
     V2_MFMA3(0, 2) V2_MFMA3(0, 3)
     __builtin_amdgcn_sched_barrier(0);
-    if (more) GLDS16(pc.al, pc.base + 8192);
+    if (more) dma(1);
     __builtin_amdgcn_sched_barrier(0);
     V2_MFMA3(1, 0) V2_MFMA3(1, 1)
     __builtin_amdgcn_sched_barrier(0);
-    if (more) GLDS16(pc.bh, pc.base + 16384);
+    if (more) dma(2);
     __builtin_amdgcn_sched_barrier(0);
     V2_MFMA3(1, 2) V2_MFMA3(1, 3)
     __builtin_amdgcn_sched_barrier(0);
-    if (more) GLDS16(pc.bl, pc.base + 24576);
+    if (more) dma(3);
     __builtin_amdgcn_sched_barrier(0);
 #undef V2_MFMA3
   };
@@ -245,9 +265,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v2_kernel(const GemmV2P q) {
     }
   }
   __syncthreads();
-  if (q.dbg & 32) { if (acc[0][0][0] == 123.456f) p.y[tid] = acc[1][1][1]; return; }
-  if (q.dbg & 64) { gemm_epilogue_t<2, 4>(p, acc, bm * 256 + wm * 64, bn * 256 + wn * 128, h, j); return; }
-  gemm_epilogue_lds<4, 2, 2, 4>(p, acc, reinterpret_cast<float*>(smv2), bm * 256, bn * 256, wm, wn, wave, lane);
+  gemm_epilogue_lds<4, WNW, 2, 4>(p, acc, reinterpret_cast<float*>(smv2), bm * 256, bn * BN, wm, wn, wave, lane);
 }
 
 // ---- per-stream scratch for the activation planes (grow-only) ----
@@ -294,27 +312,39 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
     q.g.y_hi = static_cast<__bf16*>(a.y_planes);
     q.g.y_lo = q.g.y_hi + plane_elems(a.M, n_out);
   }
+  // tile width: 256 columns on one 8-wave workgroup per CU, or 128 columns on two 4-wave workgroups per CU
+  static const int cfg_env = getenv("IDXTTS_V2_CFG") ? atoi(getenv("IDXTTS_V2_CFG")) : -1;
+  const bool narrow = cfg_env == 1;      // measured 1.5x slower on every hot-path shape (profiles/r01_gemm_bench.txt): kept for experiments
+  const int BN = narrow ? 128 : 256;
   q.g.mtiles = cdiv(a.M, 256);
   q.g.mt8 = cdiv(q.g.mtiles, 8);
-  q.g.nblocks = cdiv(w.N, 256);
+  q.g.nblocks = cdiv(w.N, BN);
   q.a_hi = hi; q.a_lo = lo; q.a_rows = a.M;
   q.npad = cdiv(w.N, 256) * 256;
   q.b_hi = static_cast<const __bf16*>(wplanes);
   q.b_lo = q.b_hi + (size_t)(w.K / 16) * q.npad * 16;
   q.zeros = g_zero_page;
   q.nstages = w.K / 16;
-  static const int dbg = getenv("IDXTTS_V2_DBG") ? atoi(getenv("IDXTTS_V2_DBG")) : 0;
-  q.dbg = dbg;
   const int64_t grid = (int64_t)8 * q.g.nblocks * q.g.mt8;
   IDX_CHECK(grid < (1ll << 31), "grid size");
-  constexpr int lds = V2_NSTAGE * V2_STAGE_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
-  }
   ProfScope prof(PROF_GEMM_BF16X3_256x256, stream, flops, bytes);
-  hipLaunchKernelGGL(gemm_bf16x3_v2_kernel, dim3((unsigned)grid), dim3(512), lds, stream, q);
+  if (narrow) {
+    constexpr int lds = 3 * (2 * 256 * 32 + 2 * 128 * 32);
+    static bool attr_set = false;
+    if (!attr_set) {
+      IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v2_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16x3_v2_kernel<1, 3>), dim3((unsigned)grid), dim3(256), lds, stream, q);
+  } else {
+    constexpr int lds = 4 * (2 * 256 * 32 + 2 * 256 * 32);
+    static bool attr_set = false;
+    if (!attr_set) {
+      IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v2_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16x3_v2_kernel<2, 4>), dim3((unsigned)grid), dim3(512), lds, stream, q);
+  }
   IDX_LAUNCH_CHECK();
   return 0;
 }
