@@ -28,6 +28,9 @@ struct GemmArgs {
   //   y_planes: the epilogue also writes its output as planes for the next GEMM; y may then be null
   const void* x_planes = nullptr;
   void* y_planes = nullptr;
+  // optional rotary embedding fused into the epilogue (LDS-DMA kernel only: check gemm_uses_planes): output columns
+  // < rope_cols are (even, odd) pairs rotated by rope[(m % rope_T)][(col / 2) % 32] = (cos, sin)
+  const float* rope = nullptr; int rope_T = 0, rope_cols = 0;
   const float* res = nullptr; int ldr = 0;    // optional residual added after the activation
   // optional per-row-group modulation of the OUTPUT (adaLN etc. are handled by the norm kernels, not here)
   int M = 0;

@@ -183,8 +183,8 @@ int gemm_tn_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t strea
   }
   if (a.row_len) IDX_CHECK(a.seq_len > 0, "row_len needs seq_len");
   GemmKP p;
-  IDX_CHECK(a.x && a.y && !a.y_planes, "the fp32 GEMM takes and produces fp32 rows only");
-  p.x = a.x; p.wp = w.wp; p.bias = w.bias; p.res = a.res; p.y = a.y; p.y_hi = p.y_lo = nullptr;
+  IDX_CHECK(a.x && a.y && !a.y_planes && !a.rope, "the fp32 GEMM takes and produces fp32 rows only (no fused rotary)");
+  p.x = a.x; p.wp = w.wp; p.bias = w.bias; p.res = a.res; p.y = a.y; p.y_hi = p.y_lo = nullptr; p.rope = nullptr; p.rope_T = 1; p.rope_cols = 0;
   p.M = a.M; p.N = w.N; p.K = w.K; p.ldx = a.ldx; p.ldy = a.ldy; p.ldr = a.ldr;
   p.kc16 = cdiv(w.K, 16);
   p.mtiles = cdiv(a.M, 128);

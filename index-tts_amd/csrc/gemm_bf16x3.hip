@@ -368,7 +368,7 @@ int gemm_bf16x3_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t s
   IDX_CHECK(a.M > 0 && w.N > 0 && w.K > 0, "bad shape");
   IDX_CHECK((w.K & 3) == 0 && (a.ldx & 3) == 0, "K and ldx must be multiples of 4");
   IDX_CHECK((reinterpret_cast<uintptr_t>(a.x) & 15) == 0, "x must be 16-byte aligned");
-  if (a.x_planes || a.y_planes || !a.x || !a.y) IDX_CHECK(gemm_bf16x3_uses_v2(w, a), "operand planes are only understood by the LDS-DMA kernel (shape not eligible)");
+  if (a.x_planes || a.y_planes || !a.x || !a.y || a.rope) IDX_CHECK(gemm_bf16x3_uses_v2(w, a), "operand planes are only understood by the LDS-DMA kernel (shape not eligible)");
   if (a.act == ACT_SWIGLU || a.act == ACT_GATE) IDX_CHECK((w.N & 63) == 0, "paired activations need N % 64 == 0");
   if (a.taps > 1) {
     IDX_CHECK(a.seq_len > 0 && a.M % a.seq_len == 0 && w.K % a.taps == 0 && ((w.K / a.taps) & 31) == 0, "conv mode shape");
@@ -376,7 +376,7 @@ int gemm_bf16x3_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t s
   }
   if (a.row_len) IDX_CHECK(a.seq_len > 0, "row_len needs seq_len");
   GemmKP p;
-  p.x = a.x; p.wp = reinterpret_cast<const float*>(w.wp16); p.bias = w.bias; p.res = a.res; p.y = a.y; p.y_hi = p.y_lo = nullptr;
+  p.x = a.x; p.wp = reinterpret_cast<const float*>(w.wp16); p.bias = w.bias; p.res = a.res; p.y = a.y; p.y_hi = p.y_lo = nullptr; p.rope = nullptr; p.rope_T = 1; p.rope_cols = 0;
   p.M = a.M; p.N = w.N; p.K = w.K; p.ldx = a.ldx; p.ldy = a.ldy; p.ldr = a.ldr;
   p.kc16 = cdiv(w.K, 16);
   p.mtiles = cdiv(a.M, 128);

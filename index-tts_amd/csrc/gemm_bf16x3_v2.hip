@@ -312,6 +312,10 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
     q.g.y_hi = static_cast<__bf16*>(a.y_planes);
     q.g.y_lo = q.g.y_hi + plane_elems(a.M, n_out);
   }
+  if (a.rope) {
+    IDX_CHECK(a.rope_T > 0 && a.rope_cols % 64 == 0 && a.act == ACT_NONE && (a.ldy & 3) == 0, "fused rotary arguments");
+    q.g.rope = a.rope; q.g.rope_T = a.rope_T; q.g.rope_cols = a.rope_cols;
+  }
   // tile width: 256 columns on one 8-wave workgroup per CU, or 128 columns on two 4-wave workgroups per CU
   static const int cfg_env = getenv("IDXTTS_V2_CFG") ? atoi(getenv("IDXTTS_V2_CFG")) : -1;
   const bool narrow = cfg_env == 1;      // measured 1.5x slower on every hot-path shape (profiles/r01_gemm_bench.txt): kept for experiments

@@ -17,6 +17,9 @@ struct GemmKP {
   int taps, kc, seq_len, dil, pad_left, pad_mode;
   const int* row_len;
   __bf16* y_hi; __bf16* y_lo;      // optional split-bf16 planes of the output ([N_out/16][M][16]); y may be null then
+  // optional fused rotary embedding (gemm_epilogue_lds only): columns < rope_cols are (even, odd) pairs rotated by
+  // rope[(m % rope_T)][(col / 2) % 32] = (cos, sin)   (gpt_fast/model.py apply_rotary_emb on q and k of a fused qkv)
+  const float* rope; int rope_T; int rope_cols;
 };
 
 
@@ -154,6 +157,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmKP& p, f32x16 (&acc)
       } else if (p.act != ACT_NONE) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act);
+      }
+      if (p.rope && n_out < p.rope_cols) {       // two (even, odd) pairs per lane
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rope + ((size_t)(m % p.rope_T) * 32 + ((n_out >> 1) & 31)) * 2);
+        v = f32x4{v[0] * cs[0] - v[1] * cs[1], v[1] * cs[0] + v[0] * cs[1], v[2] * cs[2] - v[3] * cs[3], v[3] * cs[2] + v[2] * cs[3]};
       }
       v *= p.out_scale;
       bool masked = false;

@@ -366,8 +366,14 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
       h = dst;
     }
     if (ada(h, B.attn_g, 2 * i)) return 1;
-    if (gemm(B.wqkv, w.hn, D, w.qkv, 3 * D, M, st, ACT_NONE, nullptr, 0, hn_p)) return 1;
-    if (rotary_qk(w.qkv, M, c.num_heads, T, m.rope, st)) return 1;
+    {     // qkv projection; the rotary embedding of q and k rides in its epilogue when the LDS-DMA kernel runs it
+      GemmArgs g;
+      g.x = chain ? nullptr : w.hn; g.x_planes = hn_p; g.ldx = D; g.y = w.qkv; g.ldy = 3 * D; g.M = M;
+      const bool fuse_rope = gemm_uses_planes(B.wqkv, g);
+      if (fuse_rope) { g.rope = m.rope; g.rope_T = T; g.rope_cols = 2 * D; }
+      if (gemm_forward(B.wqkv, g, st)) return 1;
+      if (!fuse_rope && rotary_qk(w.qkv, M, c.num_heads, T, m.rope, st)) return 1;
+    }
     AttnArgs a;
     a.q = w.qkv; a.k = w.qkv + D; a.v = w.qkv + 2 * D; a.o = w.att;
     a.q_bs = a.k_bs = a.v_bs = (long)T * 3 * D; a.o_bs = (long)T * D;

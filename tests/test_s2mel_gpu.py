@@ -142,3 +142,32 @@ def test_cfm_split_bf16_mode_vs_oracle(device, golden_dir):
     assert res["f32"].max().item() <= 3e-4 and res["f32"].mean().item() <= 2e-5
     assert res["bf16x3"].mean().item() <= 1e-4 and res["bf16x3"].max().item() <= 3e-3      # bound: mel L1 <= 1e-3
     assert res["bf16x3"].mean().item() > 0
+
+
+def test_cfm_long_batch_dma_gemm_chain_vs_oracle(device):
+    """2B*T >= 4096 rows and every projection >= 192 columns: the DiT / WaveNet GEMMs run on the LDS-DMA split-bf16 kernel,
+    producers hand their outputs over as bf16 hi/lo planes (adaLN norm, attention, SwiGLU and gate epilogues), the rotary
+    embedding rides in the qkv epilogue and attention runs in its split-bf16 form -- against the fp32 CPU oracle, ragged."""
+    import dataclasses
+    from indextts_amd.s2mel import S2Mel
+    from oracle import s2mel as osm
+    cfg = dataclasses.replace(S2MelConfig.tiny(), hidden_dim=256, num_heads=4, depth=3, wn_hidden=256, wn_layers=2, block_size=1024)
+    w = weights.synth_s2mel_weights(cfg, tag="t/s2mel/chain")
+    sm = S2Mel(w, cfg, device=device, max_frames=1024)
+    tw = {k: torch.from_numpy(v) for k, v in w.items()}
+    lens, plens = [720, 655, 701], [60, 33, 48]
+    B, T, Tpm = 3, max(lens), max(plens)
+    z = torch.from_numpy(synth.uniform("t/s2mel/chain/z", (B, cfg.in_channels, T), 1.7))
+    mu = torch.from_numpy(synth.uniform("t/s2mel/chain/mu", (B, T, cfg.content_dim), 1.0))
+    prompt = torch.from_numpy(synth.uniform("t/s2mel/chain/prompt", (B, cfg.in_channels, Tpm), 1.0))
+    st = torch.from_numpy(synth.uniform("t/s2mel/chain/style", (B, cfg.style_dim), 1.0))
+    for b in range(B):
+        mu[b, lens[b]:] = 0
+    out = sm.cfm_inference(mu, torch.LongTensor(lens), prompt, st, None, 2, inference_cfg_rate=0.7, z=z,
+                           prompt_lens=torch.LongTensor(plens)).cpu()
+    for b in range(B):
+        Lb, Pb = lens[b], plens[b]
+        ref = osm.cfm_inference(tw, cfg, mu[b:b + 1, :Lb], torch.LongTensor([Lb]), prompt[b:b + 1, :, :Pb], st[b:b + 1],
+                                z[b:b + 1, :, :Lb], 2, 0.7)
+        err = (out[b, :, :Lb] - ref[0]).abs()
+        assert err.mean().item() <= 1e-4 and err.max().item() <= 3e-3, (b, err.mean().item(), err.max().item())
