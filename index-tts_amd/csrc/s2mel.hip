@@ -272,6 +272,8 @@ struct Carver2 {
 struct CfmBuffers {
   float *x_in, *ha, *hb, *hmid, *hn, *qkv, *att, *ff, *xres, *wn_x, *wn_acts, *wn_out, *vout, *condp, *xstate;
   void *hn_p, *att_p, *ff_p, *acts_p;     // split-bf16 planes of hn / att / ff / wn_acts (producers write them for the next GEMM)
+  void *h_p, *wnx_p, *xres_p;             // planes of the residual stream entering a skip-receive layer, of wn_x, of xres
+  std::vector<void*> skips_p;             // planes of the U-ViT skip tensors
   std::vector<float*> skips;
   float *t1, *t1s, *mods, *fmod, *t2, *wnb, *tmp_steps;
   int *lens2, *plen;
@@ -298,6 +300,9 @@ static CfmBuffers carve_cfm(const S2MelModel& m, void* ws, int B, int T, int n_s
   b.att_p = k.take<float>(M2 * D);
   b.ff_p = k.take<float>(M2 * m.ffn);
   b.acts_p = k.take<float>(M2 * Wh);
+  b.h_p = k.take<float>(M2 * D);
+  b.wnx_p = k.take<float>(M2 * Wh);
+  b.xres_p = k.take<float>(M2 * D);
   b.wn_x = k.take<float>(M2 * Wh);
   b.wn_acts = k.take<float>(M2 * Wh);
   b.wn_out = k.take<float>(M2 * Wh);
@@ -305,6 +310,7 @@ static CfmBuffers carve_cfm(const S2MelModel& m, void* ws, int B, int T, int n_s
   b.condp = k.take<float>((size_t)B * T * D);
   b.xstate = k.take<float>((size_t)B * C * T);
   for (int i = 0; i < c.depth / 2; ++i) b.skips.push_back(k.take<float>(M2 * D));
+  for (int i = 0; i < c.depth / 2; ++i) b.skips_p.push_back(k.take<float>(M2 * D));
   b.t1 = k.take<float>((size_t)n_steps * D);
   b.t1s = k.take<float>((size_t)n_steps * D);
   b.tmp_steps = k.take<float>((size_t)n_steps * std::max(D, Wh));
@@ -345,6 +351,15 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
                                    &m.wn[0].skip};
     for (const LinearWeights* lw : used) chain = chain && gemm_uses_planes(*lw, pr);
   }
+  bool chain_wn = chain;      // the same for the long skip and the WaveNet operands (xres, wn_x)
+  {
+    GemmArgs pr;
+    pr.M = M;
+    const LinearWeights* used[] = {&m.skiplin_b, &m.conv1, &m.res_proj, &m.wn[0].res};
+    for (const LinearWeights* lw : used) chain_wn = chain_wn && gemm_uses_planes(*lw, pr);
+    pr.taps = c.wn_kernel; pr.seq_len = T;
+    chain_wn = chain_wn && gemm_uses_planes(m.wn[0].in_gate, pr);
+  }
   float* const hn_f = chain ? nullptr : w.hn;
   void* const hn_p = chain ? w.hn_p : nullptr;
   auto ada = [&](const float* x, const float* g, int mod_idx) {
@@ -360,9 +375,10 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
     DiTBlock& B = m.blocks[i];
     if (i > half) {     // U-ViT receive: skip_in_linear(cat[x, skip]) as two GEMMs (model.py:233-234)
       float* skip = w.skips[--pushed];
-      if (gemm(B.skip_a, h, D, w.hmid, D, M, st)) return 1;
+      void* skip_p = chain ? w.skips_p[pushed] : nullptr;
+      if (gemm(B.skip_a, h, D, w.hmid, D, M, st, ACT_NONE, nullptr, 0, chain ? w.h_p : nullptr)) return 1;
       float* dst = (h == w.ha) ? w.hb : w.ha;
-      if (gemm(B.skip_b, skip, D, dst, D, M, st, ACT_NONE, w.hmid, D)) return 1;
+      if (gemm(B.skip_b, skip, D, dst, D, M, st, ACT_NONE, w.hmid, D, skip_p)) return 1;
       h = dst;
     }
     if (ada(h, B.attn_g, 2 * i)) return 1;
@@ -386,15 +402,17 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
     if (ada(w.hmid, B.ffn_g, 2 * i + 1)) return 1;
     if (gemm(B.w13, w.hn, D, chain ? nullptr : w.ff, m.ffn, M, st, ACT_SWIGLU, nullptr, 0, hn_p, chain ? w.ff_p : nullptr)) return 1;
     float* dst = (i < half) ? w.skips[pushed] : ((h == w.ha) ? w.hb : w.ha);
-    if (gemm(B.w2, w.ff, m.ffn, dst, D, M, st, ACT_NONE, w.hmid, D, chain ? w.ff_p : nullptr)) return 1;      // out = h + ffn
+    // its output is read again as a GEMM operand when it is a skip tensor (skip_b later) or enters a skip-receive layer (skip_a)
+    void* dst_p = !chain ? nullptr : (i < half ? w.skips_p[pushed] : (i + 1 < depth && i + 1 > half ? w.h_p : nullptr));
+    if (gemm(B.w2, w.ff, m.ffn, dst, D, M, st, ACT_NONE, w.hmid, D, chain ? w.ff_p : nullptr, dst_p)) return 1;      // out = h + ffn
     if (i < half) ++pushed;
     h = dst;
   }
   if (ada(h, m.final_g, 2 * depth)) return 1;
   // long skip: skip_linear(cat[x_res, x]) (diffusion_transformer.py:243-244); x rows live in x_in[:, :C]
   if (gemm(m.skiplin_a, w.hn, D, w.hmid, D, M, st, ACT_NONE, nullptr, 0, hn_p)) return 1;
-  if (gemm(m.skiplin_b, w.x_in, Win, w.xres, D, M, st, ACT_NONE, w.hmid, D)) return 1;
-  if (gemm(m.conv1, w.xres, D, w.wn_x, Wh, M, st)) return 1;
+  if (gemm(m.skiplin_b, w.x_in, Win, w.xres, D, M, st, ACT_NONE, w.hmid, D, nullptr, chain_wn ? w.xres_p : nullptr)) return 1;
+  if (gemm(m.conv1, w.xres, D, w.wn_x, Wh, M, st, ACT_NONE, nullptr, 0, chain_wn ? w.xres_p : nullptr, chain_wn ? w.wnx_p : nullptr)) return 1;
   // WaveNet (wavenet.py:138-166)
   const int L = c.wn_layers, k = c.wn_kernel;
   for (int l = 0; l < L; ++l) {
@@ -404,12 +422,12 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
     LinearWeights in = W.in_gate;
     in.bias = w.wnb + ((size_t)step * L + l) * 2 * Wh;     // in_layer bias + g_l of this step, gate-packed
     GemmArgs g;
-    g.x = w.wn_x; g.ldx = Wh; g.y = chain ? nullptr : w.wn_acts; g.y_planes = chain ? w.acts_p : nullptr; g.ldy = Wh; g.M = M; g.act = ACT_GATE;
+    g.x = chain_wn ? nullptr : w.wn_x; g.x_planes = chain_wn ? w.wnx_p : nullptr; g.ldx = Wh; g.y = chain ? nullptr : w.wn_acts; g.y_planes = chain ? w.acts_p : nullptr; g.ldy = Wh; g.M = M; g.act = ACT_GATE;
     g.taps = k; g.seq_len = T; g.dil = dil; g.pad_left = (k - 1) / 2 * dil; g.pad_mode = 1; g.row_len = w.lens2;
     if (gemm_forward(in, g, st)) return 1;
     if (W.has_res) {   // x = (x + res) * mask
       GemmArgs r;
-      r.x = chain ? nullptr : w.wn_acts; r.x_planes = chain ? w.acts_p : nullptr; r.ldx = Wh; r.y = w.wn_x; r.ldy = Wh; r.res = w.wn_x; r.ldr = Wh; r.M = M; r.seq_len = T; r.row_len = w.lens2;
+      r.x = chain ? nullptr : w.wn_acts; r.x_planes = chain ? w.acts_p : nullptr; r.ldx = Wh; r.y = w.wn_x; r.y_planes = chain_wn ? w.wnx_p : nullptr; r.ldy = Wh; r.res = w.wn_x; r.ldr = Wh; r.M = M; r.seq_len = T; r.row_len = w.lens2;
       if (gemm_forward(W.res, r, st)) return 1;
     }
     GemmArgs s;        // output += skip ; the last layer's epilogue applies "* x_mask" to the finished sum
@@ -418,7 +436,7 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
     if (l == L - 1) { s.seq_len = T; s.row_len = w.lens2; }
     if (gemm_forward(W.skip, s, st)) return 1;
   }
-  if (gemm(m.res_proj, w.xres, D, w.hmid, Wh, M, st, ACT_NONE, w.wn_out, Wh)) return 1;
+  if (gemm(m.res_proj, w.xres, D, w.hmid, Wh, M, st, ACT_NONE, w.wn_out, Wh, chain_wn ? w.xres_p : nullptr)) return 1;
   {
     RowsNormArgs n;     // FinalLayer (diffusion_transformer.py:96-101)
     n.x_in = w.hmid; n.ld_in = Wh; n.y = hn_f; n.y_planes = hn_p; n.ld_y = Wh; n.M = M; n.d = Wh; n.mode = NORM_MOD_LN; n.eps = 1e-6f;
