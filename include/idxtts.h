@@ -98,9 +98,10 @@ int idxtts_linear_create(const float* weight, const float* bias /* may be NULL *
 int idxtts_linear_fwd(const idxtts_linear* lin, const float* x, int ldx, float* y, int ldy, const float* residual /* may be NULL */,
                       int ldr, int M, int act, int bf16x3 /* 0: exact fp32 MFMA, 1: split-bf16 (3 bf16 MFMAs per product) */,
                       void* stream);
-/* Arithmetic of the GEMM-shaped passes of the model contexts (s2mel, GPT latent pass): 0 = exact fp32 MFMA,
- * 1 (default) = split-bf16: x*w ~= hi*hi' + hi*lo' + lo*hi' on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
- * (relative product error ~2^-16).  The KV-cached greedy decode and its prefill are always exact fp32. */
+/* Arithmetic of the compute-bound passes of the model contexts (s2mel GEMMs and DiT attention, GPT latent pass, vocoder
+ * convolutions): 0 = exact fp32 MFMA, 1 (default) = split-bf16: x*w ~= hi*hi' + hi*lo' + lo*hi' on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation (relative product error ~2^-16; mel / waveform stay ~1e-5 from the fp32
+ * reference).  The KV-cached greedy decode and its prefill are always exact fp32 (token indices are bit-exact in both modes). */
 int idxtts_set_gemm_mode(int mode);
 int idxtts_get_gemm_mode(void);
 int idxtts_linear_destroy(idxtts_linear* lin);
