@@ -72,12 +72,16 @@ __device__ __forceinline__ float gelu_new_fx(float v) {
 }
 
 // UN = chunks per register batch (two batches live: the next one is in flight while the current one is multiplied)
-template <int MT, int NTW>
-struct FXCfg { static constexpr int UN = (MT + NTW == 2) ? 5 : (NTW == 2 ? 3 : (MT == 2 ? 2 : 1)); };
+// SINGLE: the whole K-slice of a wave fits one register batch (every GPT-2 decode shape: K / 16 waves = 5 chunks, the long
+// K of mlp.c_proj is split across workgroups): no second register set, which keeps the 16-row kernels at <= 64 VGPRs so
+// TWO 1024-thread workgroups fit a CU (8 waves per SIMD) and a 320-tile layer runs in one round.
+template <int MT, int NTW, bool SINGLE>
+struct FXCfg { static constexpr int UN = SINGLE ? 5 : ((MT + NTW == 2) ? 5 : (NTW == 2 ? 3 : (MT == 2 ? 2 : 1))); };
 
-template <int MT, int NTW>
+template <int MT, int NTW, bool SINGLE>
 __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
-  constexpr int UN = FXCfg<MT, NTW>::UN;
+  constexpr int UN = FXCfg<MT, NTW, SINGLE>::UN;
+  constexpr int NB = SINGLE ? 1 : 2;
   constexpr int NACC = MT * NTW;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* redbuf = sm;                               // [kw][NACC][256]
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
   const float* xbase = p.xf + (size_t)c0 * 256 + lane * 4;
   const size_t ximg = (size_t)p.kc16 * 256;
 
-  f32x4 wq[2][UN][NTW], xq[2][UN][MT];
+  f32x4 wq[NB][UN][NTW], xq[NB][UN][MT];
   auto load_batch = [&](int buf, int cb) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
@@ -170,12 +174,16 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
       }
     }
   };
-  for (int cb = 0; cb < nch; cb += 2 * UN) {
-    if (cb + UN < nch) load_batch(1, cb + UN);
-    consume(0, cb);
-    if (cb + UN < nch) {
-      if (cb + 2 * UN < nch) load_batch(0, cb + 2 * UN);
-      consume(1, cb + UN);
+  if constexpr (SINGLE) {
+    consume(0, 0);
+  } else {
+    for (int cb = 0; cb < nch; cb += 2 * UN) {
+      if (cb + UN < nch) load_batch(NB - 1, cb + UN);
+      consume(0, cb);
+      if (cb + UN < nch) {
+        if (cb + 2 * UN < nch) load_batch(0, cb + 2 * UN);
+        consume(NB - 1, cb + UN);
+      }
     }
   }
 
@@ -280,11 +288,13 @@ void gemv_fx_plan(int N, int K, int rows, int* ntw, int* kw) {
   const int kc16 = cdiv(K, 16), ntiles = cdiv(N, 16), MT = cdiv(rows, 16);
   int k = 16;
   while (k > 1 && kc16 < k) k >>= 1;
-  static const int ntw_min_tiles = getenv("IDXTTS_FX_NTW2_TILES") ? atoi(getenv("IDXTTS_FX_NTW2_TILES")) : 200;
   static const int kw_cap = getenv("IDXTTS_FX_KW") ? atoi(getenv("IDXTTS_FX_KW")) : 16;
   while (k > kw_cap) k >>= 1;
   *kw = k;
-  *ntw = (MT == 1 && ntiles >= ntw_min_tiles) ? 2 : 1;     // wide layers: one activation fragment feeds two column tiles
+  // Two column tiles per wave (one activation fragment feeds both) exactly when that turns a two-round launch into one
+  // round of <= 256 workgroups (c_fc: 320 tiles); measured per shape in profiles/r01_gemv_probe.txt
+  static const int force_ntw = getenv("IDXTTS_FX_NTW") ? atoi(getenv("IDXTTS_FX_NTW")) : 0;
+  *ntw = force_ntw ? (MT == 1 ? force_ntw : 1) : ((MT == 1 && ntiles > 256 && cdiv(ntiles, 2) <= 256) ? 2 : 1);
 }
 
 int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t stream) {
@@ -312,18 +322,22 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
   const double flops = 2.0 * a.rows * (double)w.N * w.K;
   const double bytes = 4.0 * ((double)w.N * w.K + (double)a.rows * w.N * (a.res ? 2.0 : 1.0) + (double)a.rows * w.K);
   ProfScope prof(PROF_GEMV16, stream, flops, bytes);
-#define LAUNCH(MTV, NTWV)                                                                                                 \
+#define LAUNCH(MTV, NTWV, SG)                                                                                             \
   {                                                                                                                       \
     static bool attr_set = false;                                                                                         \
     if (!attr_set) {                                                                                                      \
-      IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_fx_kernel<MTV, NTWV>),                               \
+      IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_fx_kernel<MTV, NTWV, SG>),                           \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                               \
       attr_set = true;                                                                                                    \
     }                                                                                                                     \
-    hipLaunchKernelGGL((gemv_fx_kernel<MTV, NTWV>), grid, dim3(threads), lds, stream, p);                                 \
+    hipLaunchKernelGGL((gemv_fx_kernel<MTV, NTWV, SG>), grid, dim3(threads), lds, stream, p);                             \
   }
-  if (MT == 1 && ntw == 2) LAUNCH(1, 2)
-  else if (MT == 1) LAUNCH(1, 1) else if (MT == 2) LAUNCH(2, 1) else if (MT == 3) LAUNCH(3, 1) else LAUNCH(4, 1)
+  const bool single = p.cps <= 5;
+  if (MT == 1 && ntw == 2 && single) LAUNCH(1, 2, true)
+  else if (MT == 1 && ntw == 2) LAUNCH(1, 2, false)
+  else if (MT == 1 && single) LAUNCH(1, 1, true)
+  else if (MT == 1) LAUNCH(1, 1, false)
+  else if (MT == 2) LAUNCH(2, 1, false) else if (MT == 3) LAUNCH(3, 1, false) else LAUNCH(4, 1, false)
 #undef LAUNCH
   IDX_LAUNCH_CHECK();
   return 0;
