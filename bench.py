@@ -45,7 +45,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def roofline_from_profile(prof, steps, workload="pipeline"):
+def roofline_from_profile(prof, steps, workload="pipeline", split_bf16=True):
     tot_ms = sum(v["ms"] for v in prof.values())
     for name, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
         log(f"[bench] kernel {name:22s} launches/step {v['launches'] // steps:6d}  {v['ms'] / steps:9.3f} ms/step "
@@ -54,7 +54,7 @@ def roofline_from_profile(prof, steps, workload="pipeline"):
     dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
     if dom_name.startswith(MFMA_KERNELS):
         achieved = dom["flops"] / dom["ms"] / 1e9
-        if dom_name.startswith("gemm_bf16x3"):
+        if dom_name.startswith("gemm_bf16x3") or (split_bf16 and dom_name.startswith(("conv1d_mfma", "flash_attn"))):
             # split-bf16: every algorithmic multiply-add is executed as three bf16 MFMA products, so the dense bf16 peak,
             # expressed in ALGORITHMIC flops, is 2500/3 TFLOP/s
             peak, note = PEAK_BF16_MFMA_TFLOPS / 3.0, "dense bf16 MFMA peak 2500 TFLOP/s / 3 products per fp32-class product"
@@ -277,7 +277,7 @@ def main() -> int:
         torch.cuda.synchronize()
         prof = _lib.profile_read()
         _lib.profile_enable(False)
-        roofline = roofline_from_profile(prof, nprof, args.workload)
+        roofline = roofline_from_profile(prof, nprof, args.workload, split_bf16=args.gemm != "f32")
         if stage_times_fn is not None:   # device-synchronised timers behind the reference's four stage names (infer_v2.py:895-901)
             stages = {k: round(v, 4) for k, v in stage_times_fn().items()}
             log(f"[bench] stage seconds (synchronised, one step): {stages}")
@@ -287,8 +287,13 @@ def main() -> int:
         cpu_baseline = cpu_leg()
 
     if rank == 0:
-        dtype = "f32" if (args.workload == "vocoder" or _lib.get_gemm_mode() == 0) else \
-            "f32 (greedy decode, prefill, attention, vocoder: exact fp32 MFMA) + split-bf16 GEMMs (hi+lo, 3 bf16 MFMAs per product, fp32 accumulate) in s2mel and the latent pass"
+        if _lib.get_gemm_mode() == 0:
+            dtype = "f32"
+        elif args.workload == "vocoder":
+            dtype = "f32 (split-bf16 convolutions: fp32 operands as hi+lo bf16, 3 bf16 MFMAs per product, fp32 accumulate; activations exact fp32)"
+        else:
+            dtype = ("f32 (greedy decode + its prefill: exact fp32 MFMA; fp32 accumulate and fp32 activations everywhere) + split-bf16 "
+                     "(fp32 operands as hi+lo bf16, 3 bf16 MFMAs per product) GEMMs, DiT attention and convolutions in s2mel, the latent pass and the vocoder")
         audio_total = audio_s_per_step_per_gpu * world * args.steps
         value = audio_total / elapsed
         cfgd = dict(desc)
