@@ -150,6 +150,23 @@ int idxtts_gpt_embed(idxtts_ctx* ctx, float* out, int rows, const int* text_ids,
 int idxtts_gpt_generate(idxtts_ctx* ctx, const float* inputs_embeds, const int* pad_left, int B, int P, int max_new_tokens,
                         float repetition_penalty, long long* codes, int* n_steps, float* logits_out, void* workspace,
                         size_t workspace_bytes, int use_graph, void* stream);
+/* The same generation loop with multinomial sampling instead of argmax (reference default do_sample=True,
+ * infer_v2.py:714-722; HF _sample transformers_generation_utils.py:3196-3262 with the warpers of 1036-1044):
+ *   mode 1: repetition penalty -> / temperature -> top-k -> top-p -> softmax -> torch.multinomial(probs, 1);
+ *   mode 2: the accel engine's Sampler (accel/accel_engine.py:648-659): softmax(logits / temperature) / clamp_min(q, 1e-10), argmax.
+ * torch.multinomial with one draw per row is argmax(probs / q), q ~ Exp(1) from ONE exponential_() call on a [B][V] tensor
+ * per step: the caller supplies those draws (exp_noise, device fp32 [max_new_tokens][B][V]), so a seeded torch generator on
+ * the host side reproduces the reference token for token.  Beam search (num_beams > 1) is not covered. */
+typedef struct idxtts_sampling {
+  int mode;              /* 0 greedy (as idxtts_gpt_generate), 1 HF multinomial with warpers, 2 accel-engine sampler */
+  float temperature;     /* > 0 */
+  int top_k;             /* 0 = off */
+  float top_p;           /* >= 1 = off; < 1 needs 0 < top_k <= 1024 */
+  const float* exp_noise;
+} idxtts_sampling;
+int idxtts_gpt_generate_sampled(idxtts_ctx* ctx, const float* inputs_embeds, const int* pad_left, int B, int P, int max_new_tokens,
+                                float repetition_penalty, const idxtts_sampling* sampling, long long* codes, int* n_steps,
+                                float* logits_out, void* workspace, size_t workspace_bytes, int use_graph, void* stream);
 /* Latent pass: full causal forward over emb [B][S][d]; latent[b][i] = final_norm(ln_f(h[b][mel_start + i])), i < M.
  * pad_left: optional HOST int32 [B], leading rows of each sequence that are padding (masked as keys), so rows with
  * shorter texts can share a batch and still reproduce the reference's per-utterance (B=1) result. */

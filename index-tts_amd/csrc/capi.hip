@@ -305,7 +305,18 @@ int idxtts_gpt_generate(idxtts_ctx* ctx, const float* inputs_embeds, const int* 
                         size_t workspace_bytes, int use_graph, void* stream) {
   API_BEGIN
   GPT_MODEL(ctx);
-  return m->generate(inputs_embeds, pad_left, B, P, max_new_tokens, repetition_penalty, codes, n_steps, logits_out, workspace,
+  return m->generate(inputs_embeds, pad_left, B, P, max_new_tokens, repetition_penalty, nullptr, codes, n_steps, logits_out, workspace,
+                     workspace_bytes, use_graph, static_cast<hipStream_t>(stream));
+  API_END
+}
+
+int idxtts_gpt_generate_sampled(idxtts_ctx* ctx, const float* inputs_embeds, const int* pad_left, int B, int P, int max_new_tokens,
+                                float repetition_penalty, const idxtts_sampling* sampling, long long* codes, int* n_steps,
+                                float* logits_out, void* workspace, size_t workspace_bytes, int use_graph, void* stream) {
+  API_BEGIN
+  GPT_MODEL(ctx);
+  IDX_CHECK(sampling, "null sampling configuration");
+  return m->generate(inputs_embeds, pad_left, B, P, max_new_tokens, repetition_penalty, sampling, codes, n_steps, logits_out, workspace,
                      workspace_bytes, use_graph, static_cast<hipStream_t>(stream));
   API_END
 }

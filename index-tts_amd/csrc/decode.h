@@ -36,6 +36,23 @@ struct SampleArgs {
 };
 int sample_greedy_forward(const SampleArgs& a, hipStream_t stream);
 
+// Multinomial sampling of the next token (HF _sample, transformers_generation_utils.py:3222-3250, with the warpers of
+// 1036-1044): repetition penalty -> / temperature -> top-k (ties at the threshold kept) -> top-p (ascending sort, softmax,
+// cumulative <= 1 - top_p removed, largest always kept) -> softmax -> torch.multinomial(probs, 1), which IS
+// argmax(probs / q) with q ~ Exp(1): the draw is an explicit input, exp_noise[step][b][V].
+// mode SAMPLE_ACCEL restates the accel engine's Sampler instead (accel_engine.py:648-659): softmax(logits / T) divided by
+// clamp_min(q, 1e-10), argmax; no penalty, no top-k / top-p.
+enum SampleMode { SAMPLE_HF = 1, SAMPLE_ACCEL = 2 };
+struct SampleWarpArgs {
+  SampleArgs base;                   // logits source, bookkeeping buffers, penalty (parts must be 1)
+  int mode = SAMPLE_HF;
+  float temperature = 1.0f;
+  int top_k = 0;                     // 0 = off
+  float top_p = 1.0f;                // >= 1 = off
+  const float* exp_noise = nullptr;  // [steps][B][V]
+};
+int sample_warp_forward(const SampleWarpArgs& a, hipStream_t stream);
+
 int advance_state(DecodeState* st, hipStream_t stream);
 int kv_store_prefill(const float* qkv, float* kcache, float* vcache, int B, int H, int S, int Smax, int d, hipStream_t stream);
 constexpr int GATHER_MAX_TABLES = 5;

@@ -235,6 +235,179 @@ int sample_greedy_forward(const SampleArgs& a, hipStream_t stream) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// -------------------------------------------------------------------------------------------------
+// multinomial sampling with the HF warpers / the accel-engine sampler (SampleWarpArgs, decode.h)
+constexpr int SW_NPT = 16;          // vocabulary entries per thread: V <= 16384
+constexpr int SW_CAP = 2048;        // survivors of the top-k filter handled by the top-p stage (more only on massive ties)
+
+__device__ __forceinline__ void block_argmax(float& v, int& i, float* rv, int* ri, int tid) {
+  // max value, smallest index on ties; result broadcast to every thread
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(v, off);
+    const int oi = __shfl_xor(i, off);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) { rv[tid >> 6] = v; ri[tid >> 6] = i; }
+  __syncthreads();
+  v = rv[0]; i = ri[0];
+  for (int w = 1; w < 16; ++w)
+    if (rv[w] > v || (rv[w] == v && ri[w] < i)) { v = rv[w]; i = ri[w]; }
+}
+
+__global__ __launch_bounds__(1024) void sample_warp_kernel(const SampleWarpArgs q) {
+  const SampleArgs& p = q.base;
+  __shared__ float rv[16];
+  __shared__ int ri[16];
+  __shared__ float sval[SW_CAP];
+  __shared__ int sidx[SW_CAP];
+  __shared__ float sorted_v[SW_CAP];
+  __shared__ int sorted_i[SW_CAP];
+  __shared__ int s_count, s_keep_from;
+  __shared__ float s_sum;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int V = p.V;
+  const unsigned char* seen = p.seen + (size_t)b * V;
+  const float* prow = p.part + (size_t)b * V;
+  const float* noise = q.exp_noise + ((size_t)p.st->step * p.B + b) * V;
+
+  // ---- scores: logits -> (repetition penalty) -> / temperature ----
+  float sc[SW_NPT];
+#pragma unroll
+  for (int u = 0; u < SW_NPT; ++u) {
+    const int v = tid + 1024 * u;
+    float l = -INFINITY;
+    if (v < V) {
+      l = prow[v] + (p.bias ? p.bias[v] : 0.0f);
+      if (p.logits_out) p.logits_out[(size_t)b * V + v] = l;
+      if (q.mode == SAMPLE_HF && p.penalty != 1.0f && seen[v]) l = l < 0.f ? l * p.penalty : l / p.penalty;
+      if (q.temperature != 1.0f) l = l / q.temperature;
+    }
+    sc[u] = l;
+  }
+
+  int token;
+  if (q.mode == SAMPLE_ACCEL || (q.top_k == 0 && q.top_p >= 1.0f)) {
+    // softmax over the whole row, divided by the (accel sampler: clamped) noise, argmax
+    const float qmin = q.mode == SAMPLE_ACCEL ? 1e-10f : 0.0f;
+    float mx = -INFINITY; int mi = 0;
+#pragma unroll
+    for (int u = 0; u < SW_NPT; ++u) if (sc[u] > mx) { mx = sc[u]; mi = tid + 1024 * u; }
+    block_argmax(mx, mi, rv, ri, tid);
+    float part = 0.f;
+#pragma unroll
+    for (int u = 0; u < SW_NPT; ++u) if (tid + 1024 * u < V) part += expf(sc[u] - mx);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    __syncthreads();
+    if ((tid & 63) == 0) rv[tid >> 6] = part;
+    __syncthreads();
+    float tot = 0.f;
+    for (int w = 0; w < 16; ++w) tot += rv[w];
+    float best = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+    for (int u = 0; u < SW_NPT; ++u) {
+      const int v = tid + 1024 * u;
+      if (v < V) {
+        const float r = (expf(sc[u] - mx) / tot) / fmaxf(noise[v], qmin);
+        if (r > best) { best = r; bi = v; }
+      }
+    }
+    block_argmax(best, bi, rv, ri, tid);
+    token = bi;
+  } else {
+    // ---- top-k: the k-th largest value (with multiplicity) by k rounds of block-wide max extraction ----
+    if (q.top_k > 0 && q.top_k < V) {
+      unsigned taken = 0;
+      float kth = -INFINITY;
+      for (int r = 0; r < q.top_k; ++r) {
+        float mx = -INFINITY; int mi = 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u < SW_NPT; ++u) {
+          const int v = tid + 1024 * u;
+          if (v < V && !((taken >> u) & 1u) && (sc[u] > mx || (sc[u] == mx && v < mi))) { mx = sc[u]; mi = v; }
+        }
+        block_argmax(mx, mi, rv, ri, tid);
+        kth = mx;
+        if ((mi & 1023) == tid && mi < V) taken |= 1u << (mi >> 10);
+      }
+#pragma unroll
+      for (int u = 0; u < SW_NPT; ++u) if (sc[u] < kth) sc[u] = -INFINITY;
+    }
+    // ---- survivors -> LDS (finite scores only: -inf has probability 0 and sorts first) ----
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < SW_NPT; ++u) {
+      const int v = tid + 1024 * u;
+      if (v < V && sc[u] > -INFINITY) {
+        const int slot = atomicAdd(&s_count, 1);
+        if (slot < SW_CAP) { sval[slot] = sc[u]; sidx[slot] = v; }
+      }
+    }
+    __syncthreads();
+    const int n = min(s_count, SW_CAP);
+    // rank sort, ascending by (value, index)
+    for (int e = tid; e < n; e += 1024) {
+      const float ve = sval[e]; const int ie = sidx[e];
+      int rank = 0;
+      for (int o = 0; o < n; ++o) rank += (sval[o] < ve || (sval[o] == ve && sidx[o] < ie)) ? 1 : 0;
+      sorted_v[rank] = ve; sorted_i[rank] = ie;
+    }
+    __syncthreads();
+    // ---- top-p on the ascending list: softmax, running sum, remove while cum <= 1 - top_p (never the last one) ----
+    if (tid == 0) {
+      int keep_from = 0;
+      const float mx = sorted_v[n - 1];
+      if (q.top_p < 1.0f) {
+        float tot = 0.f;
+        for (int e = 0; e < n; ++e) tot += expf(sorted_v[e] - mx);
+        const float thr = (float)(1.0 - (double)q.top_p);
+        float cum = 0.f;
+        for (int e = 0; e < n - 1; ++e) {
+          cum += expf(sorted_v[e] - mx) / tot;
+          if (cum <= thr) keep_from = e + 1; else break;
+        }
+      }
+      float tot2 = 0.f;      // softmax denominator of the warped scores
+      for (int e = keep_from; e < n; ++e) tot2 += expf(sorted_v[e] - mx);
+      s_keep_from = keep_from;
+      s_sum = tot2;
+    }
+    __syncthreads();
+    // ---- multinomial == argmax(probs / q) over the kept tokens ----
+    const float mx = sorted_v[n - 1];
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int e = s_keep_from + tid; e < n; e += 1024) {
+      const int v = sorted_i[e];
+      const float r = (expf(sorted_v[e] - mx) / s_sum) / noise[v];
+      if (r > best || (r == best && v < bi)) { best = r; bi = v; }
+    }
+    block_argmax(best, bi, rv, ri, tid);
+    token = bi;
+  }
+  if (tid == 0) {
+    const int tok = p.finished[b] ? p.stop_token : token;
+    p.codes[(size_t)b * p.codes_ld + p.st->step] = tok;
+    p.seen[(size_t)b * V + tok] = 1;
+    if (tok == p.stop_token) p.finished[b] = 1;
+    p.cur_tok[b] = tok;
+  }
+}
+
+int sample_warp_forward(const SampleWarpArgs& a, hipStream_t stream) {
+  const SampleArgs& b = a.base;
+  IDX_CHECK(b.part && b.parts == 1 && b.seen && b.finished && b.codes && b.cur_tok && b.st && a.exp_noise, "null pointer");
+  IDX_CHECK(b.V > 0 && b.V <= 1024 * SW_NPT, "vocabulary size");
+  IDX_CHECK(a.temperature > 0.0f && a.top_k >= 0 && a.top_p > 0.0f, "sampling parameters");
+  IDX_CHECK(a.mode == SAMPLE_HF || a.mode == SAMPLE_ACCEL, "sampling mode");
+  ProfScope prof(PROF_SAMPLE, stream, 0.0, 8.0 * b.B * (double)b.V);
+  hipLaunchKernelGGL(sample_warp_kernel, dim3(b.B), dim3(1024), 0, stream, a);
+  IDX_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ void advance_state_kernel(DecodeState* st) {
   if (threadIdx.x == 0 && blockIdx.x == 0) { st->pos += 1; st->mel_pos += 1; st->step += 1; }
 }

@@ -236,6 +236,12 @@ int GPTModel::head_and_sample(const Buffers& w, int B, const float* x, int ldx, 
   s.part = w.logits; s.parts = 1; s.part_rows = B; s.bias = nullptr; s.logits_out = logits_out;
   s.seen = w.seen; s.finished = w.finished; s.codes = codes; s.codes_ld = codes_ld; s.cur_tok = w.cur_tok;
   s.st = w.state; s.B = B; s.V = V; s.stop_token = cfg.stop_mel_token; s.penalty = penalty;
+  if (samp.mode != 0) {
+    SampleWarpArgs sw;
+    sw.base = s; sw.mode = samp.mode; sw.temperature = samp.temperature; sw.top_k = samp.top_k; sw.top_p = samp.top_p;
+    sw.exp_noise = samp.exp_noise;
+    return sample_warp_forward(sw, st);
+  }
   return sample_greedy_forward(s, st);
 }
 
@@ -280,7 +286,7 @@ int GPTModel::decode_step(const Buffers& w, int B, float penalty, long long* cod
 }
 
 int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int B, int P, int max_new, float penalty,
-                       long long* codes, int* n_steps_out, float* logits_out, void* ws, size_t ws_bytes, int use_graph,
+                       const idxtts_sampling* sampling, long long* codes, int* n_steps_out, float* logits_out, void* ws, size_t ws_bytes, int use_graph,
                        hipStream_t user_stream) {
   IDX_CHECK(inputs_embeds && codes && n_steps_out, "null pointer");
   // The legacy default stream cannot be captured into a graph: run on a private stream, ordered after
@@ -292,6 +298,13 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
     st = own_stream;
   }
   IDX_CHECK(B > 0 && B <= 64 && P > 0 && max_new > 0, "shape (1 <= B <= 64)");
+  samp = idxtts_sampling{0, 1.0f, 0, 1.0f, nullptr};
+  if (sampling && sampling->mode != 0) {
+    IDX_CHECK(sampling->mode == SAMPLE_HF || sampling->mode == SAMPLE_ACCEL, "sampling mode");
+    IDX_CHECK(sampling->exp_noise && sampling->temperature > 0.0f, "sampling needs the Exp(1) draws and a positive temperature");
+    IDX_CHECK(sampling->top_p >= 1.0f || (sampling->top_k > 0 && sampling->top_k <= 1024), "top-p needs 0 < top_k <= 1024");
+    samp = *sampling;
+  }
   const int d = cfg.model_dim, V = cfg.number_mel_codes, S = P + 1;
   IDX_CHECK(max_new + 1 < cfg.mel_pos_len, "max_new_tokens exceeds the mel position table");
   IDX_CHECK(ws && ws_bytes >= workspace_bytes(B, S, max_new), "workspace too small");

@@ -20,7 +20,7 @@ SYMBOLS = [
     "idxtts_bigvgan_create", "idxtts_bigvgan_workspace_bytes", "idxtts_bigvgan_fwd",
     "idxtts_profile_enable", "idxtts_profile_num_kernels", "idxtts_profile_kernel_name", "idxtts_profile_read",
     "idxtts_linear_create", "idxtts_linear_fwd", "idxtts_linear_destroy", "idxtts_attention_fwd", "idxtts_attention_bf16x3_fwd", "idxtts_layernorm_fwd",
-    "idxtts_gpt_create", "idxtts_gpt_workspace_bytes", "idxtts_gpt_embed", "idxtts_gpt_generate", "idxtts_gpt_latent",
+    "idxtts_gpt_create", "idxtts_gpt_workspace_bytes", "idxtts_gpt_embed", "idxtts_gpt_generate", "idxtts_gpt_generate_sampled", "idxtts_gpt_latent",
     "idxtts_s2mel_create", "idxtts_s2mel_cond_workspace_bytes", "idxtts_s2mel_prepare_cond",
     "idxtts_s2mel_cfm_workspace_bytes", "idxtts_s2mel_cfm", "idxtts_set_gemm_mode", "idxtts_get_gemm_mode",
 ]
@@ -38,6 +38,10 @@ class BigVGANConfigC(ctypes.Structure):
 class GPTConfigC(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("model_dim", "heads", "layers", "number_mel_codes", "number_text_tokens",
                                      "start_mel_token", "stop_mel_token", "mel_pos_len", "text_pos_len")]
+
+
+class SamplingC(ctypes.Structure):          # idxtts_sampling (include/idxtts.h)
+    _fields_ = [("mode", c_int), ("temperature", c_float), ("top_k", c_int), ("top_p", c_float), ("exp_noise", c_void_p)]
 
 
 class S2MelConfigC(ctypes.Structure):
@@ -92,6 +96,8 @@ def load() -> ctypes.CDLL:
     lib.idxtts_gpt_embed.argtypes = [c_void_p, c_void_p, c_int] + [c_void_p] * 7
     lib.idxtts_gpt_generate.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, POINTER(c_int),
                                         c_void_p, c_void_p, c_size_t, c_int, c_void_p]
+    lib.idxtts_gpt_generate_sampled.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, POINTER(SamplingC), c_void_p,
+                                                POINTER(c_int), c_void_p, c_void_p, c_size_t, c_int, c_void_p]
     lib.idxtts_gpt_latent.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.idxtts_s2mel_create.argtypes = [POINTER(S2MelConfigC), POINTER(c_void_p)]
     lib.idxtts_s2mel_cond_workspace_bytes.argtypes = [c_void_p, c_int, c_int, c_int]

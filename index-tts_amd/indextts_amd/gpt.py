@@ -115,9 +115,18 @@ class UnifiedVoice:
     def generate(self, input_ids: torch.Tensor, max_new_tokens: int = 100, temperature: float = 1.0, top_k: int = 50,
                  top_p: float = 1.0, stop_tokens=None, attention_mask: Optional[torch.Tensor] = None,
                  tts_embeddings: Optional[torch.Tensor] = None, tts_mel_embedding=None, tts_text_pos_embedding=None,
-                 repetition_penalty: float = 10.0, return_logits: bool = False, use_graph: bool = True) -> torch.Tensor:
+                 repetition_penalty: float = 10.0, return_logits: bool = False, use_graph: bool = True,
+                 do_sample: bool = False, sampler: str = "hf", exp_noise: Optional[torch.Tensor] = None,
+                 generator: Optional[torch.Generator] = None) -> torch.Tensor:
         """The accel-engine plugin contract (accel_engine.py:378-645): returns LongTensor [B, P+1+generated]
-        (prompt ids followed by the generated codes, padded with the stop token).  Greedy only."""
+        (prompt ids followed by the generated codes, padded with the stop token).
+
+        do_sample=False: greedy (temperature / top_k / top_p ignored).  do_sample=True: multinomial sampling,
+        sampler="hf" = HF `_sample` with its warpers (repetition penalty -> temperature -> top-k -> top-p -> multinomial,
+        transformers_generation_utils.py:1036-1044, 3222-3250), sampler="accel" = the accel engine's own Sampler
+        (softmax(logits / T) / Exp(1) noise, argmax; accel_engine.py:648-659).  torch.multinomial(probs, 1) is
+        argmax(probs / q) with q ~ Exp(1): `exp_noise` [max_new_tokens, B, V] supplies the draws; when omitted they are
+        drawn on the CPU from `generator` (or the global RNG) with one exponential_() per step, the order HF consumes them."""
         if tts_embeddings is None:
             raise ValueError("tts_embeddings ([pad][cond][text] prompt embeddings) is required")
         if stop_tokens is not None and list(stop_tokens) != [self.cfg.stop_mel_token]:
@@ -135,9 +144,26 @@ class UnifiedVoice:
         logits = torch.zeros(max_new_tokens, B, V, device=self.device) if return_logits else None
         ws = self._workspace(B, P + 1, max_new_tokens)
         n = ctypes.c_int(0)
-        _lib.check(_lib.load().idxtts_gpt_generate(
-            self._h, _lib.ptr(emb), pad_left.ctypes.data_as(c_void_p), B, P, max_new_tokens, float(repetition_penalty),
-            _lib.ptr(codes), ctypes.byref(n), _lib.ptr(logits), _lib.ptr(ws), ws.numel(), int(use_graph), _lib.current_stream()))
+        if do_sample:
+            if sampler not in ("hf", "accel"):
+                raise ValueError("sampler must be 'hf' or 'accel'")
+            if exp_noise is None:
+                exp_noise = torch.stack([torch.empty(B, V).exponential_(1, generator=generator) for _ in range(max_new_tokens)])
+            if tuple(exp_noise.shape) != (max_new_tokens, B, V):
+                raise ValueError(f"exp_noise must be [max_new_tokens, B, V] = {(max_new_tokens, B, V)}")
+            noise = exp_noise.to(self.device, torch.float32).contiguous()
+            sc = _lib.SamplingC(mode=1 if sampler == "hf" else 2, temperature=float(temperature),
+                                top_k=int(top_k or 0) if sampler == "hf" else 0,
+                                top_p=float(top_p if top_p is not None else 1.0) if sampler == "hf" else 1.0,
+                                exp_noise=noise.data_ptr())
+            _lib.check(_lib.load().idxtts_gpt_generate_sampled(
+                self._h, _lib.ptr(emb), pad_left.ctypes.data_as(c_void_p), B, P, max_new_tokens, float(repetition_penalty),
+                ctypes.byref(sc), _lib.ptr(codes), ctypes.byref(n), _lib.ptr(logits), _lib.ptr(ws), ws.numel(), int(use_graph),
+                _lib.current_stream()))
+        else:
+            _lib.check(_lib.load().idxtts_gpt_generate(
+                self._h, _lib.ptr(emb), pad_left.ctypes.data_as(c_void_p), B, P, max_new_tokens, float(repetition_penalty),
+                _lib.ptr(codes), ctypes.byref(n), _lib.ptr(logits), _lib.ptr(ws), ws.numel(), int(use_graph), _lib.current_stream()))
         out = torch.cat([input_ids.to(self.device), codes[:, : n.value]], dim=1)
         if return_logits:
             return out, logits[: n.value].permute(1, 0, 2).contiguous()
@@ -145,15 +171,20 @@ class UnifiedVoice:
 
     def inference_speech(self, speech_conditioning_latent, text_inputs, emo_vec=None, max_generate_length=None,
                          num_return_sequences=1, return_logits=False, **hf_generate_kwargs):
-        """Greedy `inference_speech` (model_v2.py:796-895): returns (codes [B, n], speech_conditioning_latent)."""
-        if hf_generate_kwargs.pop("do_sample", False) or hf_generate_kwargs.pop("num_beams", 1) != 1:
-            raise NotImplementedError("only greedy decoding (do_sample=False, num_beams=1) is implemented on the HIP path "
-                                      "(beam-sample is SURVEY §8f rank 2)")
+        """`inference_speech` (model_v2.py:796-895): returns (codes [B, n], speech_conditioning_latent).
+        num_beams=1 only: greedy (do_sample=False) or multinomial sampling with HF's warpers (do_sample=True; extra kwargs
+        `exp_noise` / `generator` / `sampler`, see generate())."""
+        do_sample = bool(hf_generate_kwargs.pop("do_sample", False))
+        if hf_generate_kwargs.pop("num_beams", 1) != 1:
+            raise NotImplementedError("beam search (num_beams > 1) is not implemented on the HIP path (SURVEY §8f rank 2); "
+                                      "greedy and num_beams=1 sampling are")
         if num_return_sequences != 1:
             raise NotImplementedError("num_return_sequences must be 1")
         penalty = float(hf_generate_kwargs.pop("repetition_penalty", 1.0))
-        for k in ("top_p", "top_k", "temperature", "length_penalty"):
-            hf_generate_kwargs.pop(k, None)
+        samp = {"do_sample": do_sample, "top_p": hf_generate_kwargs.pop("top_p", 1.0), "top_k": hf_generate_kwargs.pop("top_k", 50),
+                "temperature": hf_generate_kwargs.pop("temperature", 1.0), "exp_noise": hf_generate_kwargs.pop("exp_noise", None),
+                "generator": hf_generate_kwargs.pop("generator", None), "sampler": hf_generate_kwargs.pop("sampler", "hf")}
+        hf_generate_kwargs.pop("length_penalty", None)
         if hf_generate_kwargs:
             raise TypeError(f"unsupported generate kwargs: {sorted(hf_generate_kwargs)}")
         conds = self.conds_latent(speech_conditioning_latent, emo_vec)
@@ -162,7 +193,7 @@ class UnifiedVoice:
         max_new = (self.cfg.max_mel_tokens - 1) if max_generate_length is None else int(max_generate_length)
         out = self.generate(input_ids, max_new_tokens=max_new, stop_tokens=[self.cfg.stop_mel_token],
                             attention_mask=attention_mask, tts_embeddings=inputs_embeds, repetition_penalty=penalty,
-                            return_logits=return_logits)
+                            return_logits=return_logits, **samp)
         if return_logits:
             return out[0][:, trunc_index:], speech_conditioning_latent, out[1]
         return out[:, trunc_index:], speech_conditioning_latent

@@ -119,10 +119,12 @@ class IndexTTS2:
     # ------------------------------------------------------------------------------------------
     def synthesize_batch(self, text_tokens: torch.Tensor, cond: PromptConditioning, max_mel_tokens: int = 1500,
                          repetition_penalty: float = 10.0, noise: Optional[torch.Tensor] = None, sync_timers: bool = False,
-                         return_intermediates: bool = False):
+                         return_intermediates: bool = False, sampling: Optional[dict] = None):
         """One batch of single-segment utterances sharing a prompt: the body of the reference's segment loop
         (infer_v2.py:732-881) for B rows at once.  text_tokens [B, L] (right-padded with stop_text_token).
-        Returns a list of B waveforms, float32 [1, n_b] in int16 range (infer_v2.py:866)."""
+        Returns a list of B waveforms, float32 [1, n_b] in int16 range (infer_v2.py:866).
+        sampling: None = greedy; else the num_beams=1 sampling kwargs of UnifiedVoice.inference_speech
+        (do_sample, temperature, top_k, top_p, sampler, exp_noise / generator)."""
         dev = self.device
         c = cond.to(dev)
         B = text_tokens.shape[0]
@@ -137,7 +139,8 @@ class IndexTTS2:
         lat = c.spk_cond_latent.expand(B, -1, -1) if c.spk_cond_latent.shape[0] == 1 else c.spk_cond_latent
         emo = c.emo_vec.expand(B, -1) if c.emo_vec.shape[0] == 1 else c.emo_vec
         codes, _ = self.gpt.inference_speech(lat, text_tokens, emo_vec=emo, max_generate_length=max_mel_tokens,
-                                             repetition_penalty=repetition_penalty, do_sample=False, num_beams=1)
+                                             repetition_penalty=repetition_penalty, num_beams=1,
+                                             **(sampling if sampling else {"do_sample": False}))
         t1 = tick()
         times["gpt_gen_time"] = t1 - t0
         # trim at the first stop token (infer_v2.py:795-807)
@@ -217,16 +220,23 @@ class IndexTTS2:
             return None                                                                              # infer_v2.py:566-567
         do_sample = generation_kwargs.pop("do_sample", False)
         num_beams = generation_kwargs.pop("num_beams", 1)
-        if do_sample or num_beams != 1:
-            raise NotImplementedError("only greedy decoding is implemented on the HIP path (SURVEY.md §8f rank 2)")
+        if num_beams != 1:
+            raise NotImplementedError("beam search is not implemented on the HIP path (SURVEY.md §8f rank 2): pass num_beams=1 "
+                                      "(greedy, or do_sample=True for multinomial sampling with top_k / top_p / temperature)")
         repetition_penalty = generation_kwargs.pop("repetition_penalty", 10.0)
         max_mel_tokens = generation_kwargs.pop("max_mel_tokens", 1500)
+        sampling = None
+        if do_sample:      # reference defaults: top_p 0.8, top_k 30, temperature 0.8 (infer_v2.py:715-717)
+            sampling = {"do_sample": True, "top_p": generation_kwargs.pop("top_p", 0.8), "top_k": generation_kwargs.pop("top_k", 30),
+                        "temperature": generation_kwargs.pop("temperature", 0.8), "sampler": generation_kwargs.pop("sampler", "hf"),
+                        "generator": generation_kwargs.pop("generator", None)}
         for k in ("top_p", "top_k", "temperature", "length_penalty"):
             generation_kwargs.pop(k, None)
         start = time.perf_counter()
         wavs = []
         for s in segs:                                                                               # segment loop, infer_v2.py:732
-            w = self.synthesize_batch(s, spk_audio_prompt, max_mel_tokens=max_mel_tokens, repetition_penalty=repetition_penalty)[0]
+            w = self.synthesize_batch(s, spk_audio_prompt, max_mel_tokens=max_mel_tokens, repetition_penalty=repetition_penalty,
+                                      sampling=sampling)[0]
             wavs.append(w)
         out = []
         sil = self.interval_silence(interval_silence=interval_silence)

@@ -164,6 +164,70 @@ def generate_greedy(w, cfg, conds: torch.Tensor, text_inputs: torch.Tensor, max_
     return (codes, torch.stack(all_logits, 1)) if return_logits else codes
 
 
+def warp_scores(scores: torch.Tensor, temperature: float, top_k: int, top_p: float, min_tokens_to_keep: int = 1) -> torch.Tensor:
+    """The sampling warpers HF generate() applies after the repetition penalty, in its order (reference:
+    transformers_generation_utils.py:1036-1044 builds TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper from
+    the pinned third-party `transformers` 4.52.1 logits_process.py; num_beams=1 gives min_tokens_to_keep=1, line 1031):
+      temperature: scores / T
+      top-k: remove everything strictly below the k-th largest value (ties at the threshold stay)
+      top-p: sort ascending, softmax, cumulative sum; remove where cum <= 1 - top_p, never the last min_tokens_to_keep."""
+    if temperature != 1.0:
+        scores = scores / temperature
+    if top_k and top_k > 0:
+        k = min(max(top_k, min_tokens_to_keep), scores.shape[-1])
+        kth = torch.topk(scores, k)[0][..., -1, None]
+        scores = scores.masked_fill(scores < kth, float("-inf"))
+    if top_p is not None and top_p < 1.0:
+        sorted_logits, sorted_indices = torch.sort(scores, descending=False)
+        cumulative = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
+        remove = cumulative <= (1 - top_p)
+        remove[..., -min_tokens_to_keep:] = False
+        scores = scores.masked_fill(remove.scatter(1, sorted_indices, remove), float("-inf"))
+    return scores
+
+
+def generate_sample(w, cfg, conds: torch.Tensor, text_inputs: torch.Tensor, max_new_tokens: int, exp_noise: torch.Tensor,
+                    repetition_penalty_value: float = 10.0, temperature: float = 0.8, top_k: int = 30, top_p: float = 0.8,
+                    accel_sampler: bool = False):
+    """inference_speech (model_v2.py:835-892) with do_sample=True, num_beams=1: HF _sample
+    (transformers_generation_utils.py:3196-3262): repetition penalty -> warpers -> softmax -> torch.multinomial(probs, 1).
+    torch.multinomial with one sample per row IS argmax(probs / q), q ~ Exp(1) drawn by ONE exponential_() call on a
+    [B, V] tensor (ATen native multinomial, fast path), so the draw is an explicit input here: exp_noise [steps, B, V].
+    accel_sampler=True restates the accel engine's Sampler instead (accel_engine.py:648-659): softmax(logits / T),
+    divided by clamp_min(q, 1e-10), argmax -- no repetition penalty, no top-k / top-p."""
+    fake, inputs_embeds, attention_mask = prepare_gpt_inputs(w, cfg, conds, text_inputs)
+    B, P, d = inputs_embeds.shape
+    me, mp = _t(w, "mel_embedding.weight"), _t(w, "mel_pos_embedding.emb.weight")
+    input_ids = fake.clone()
+    unfinished = torch.ones(B, dtype=torch.long)
+    past = None
+    for step in range(max_new_tokens):
+        if past is None:
+            start = (me[cfg.start_mel_token] + mp[0])[None, None, :].expand(B, 1, d)
+            emb = torch.cat([inputs_embeds, start], dim=1)
+        else:
+            pos = attention_mask.shape[1] - P
+            emb = (me[input_ids[:, -1]] + mp[pos])[:, None, :]
+        hidden, past = gpt2_stack(w, cfg, emb, attention_mask, past)
+        logits = lm_head(w, cfg, hidden[:, -1]).float()
+        q = exp_noise[step].float()
+        if accel_sampler:
+            probs = torch.softmax(logits / temperature, dim=-1)
+            nxt = (probs / q.clamp_min(1e-10)).argmax(dim=-1)
+        else:
+            scores = repetition_penalty(input_ids, logits, repetition_penalty_value) if repetition_penalty_value != 1.0 else logits
+            scores = warp_scores(scores, temperature, top_k, top_p)
+            probs = torch.softmax(scores, dim=-1)
+            nxt = (probs / q).argmax(dim=-1)
+        nxt = nxt * unfinished + cfg.stop_mel_token * (1 - unfinished)
+        input_ids = torch.cat([input_ids, nxt[:, None]], dim=1)
+        attention_mask = torch.cat([attention_mask, torch.ones(B, 1, dtype=torch.long)], dim=1)
+        unfinished = unfinished & (nxt != cfg.stop_mel_token).long()
+        if unfinished.max() == 0:
+            break
+    return input_ids[:, P + 1:]
+
+
 def latent_forward(w, cfg, speech_conditioning_latent: torch.Tensor, text_inputs: torch.Tensor,
                    mel_codes: torch.Tensor, emo_vec: torch.Tensor,
                    text_lengths: Optional[torch.Tensor] = None,

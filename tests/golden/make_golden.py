@@ -297,6 +297,40 @@ def make_gpt():
     out["greedy_codes"] = input_ids[:, P + 1:].numpy()
     out["greedy_logits"] = torch.stack(logits_all, 1).numpy()
     out["greedy_text"] = text.numpy()
+    # ---- multinomial sampling, HF warpers: same prompts, do_sample=True / num_beams=1 (transformers_generation_utils.py:
+    #      3196-3262, warpers 1036-1044), seeded; the Exp(1) draws torch.multinomial makes internally are re-drawn with the
+    #      same seed and stored, so the oracle / GPU path can be fed the identical noise ----
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    TEMP, TOPK, TOPP, SEED = 0.8, 30, 0.8, 20240607
+    warpers = [TemperatureLogitsWarper(TEMP), TopKLogitsWarper(top_k=TOPK, min_tokens_to_keep=1), TopPLogitsWarper(top_p=TOPP, min_tokens_to_keep=1)]
+    torch.manual_seed(SEED)
+    input_ids = fake.clone()
+    attention_mask = og.prepare_gpt_inputs(tw, cfg, conds, text)[2]
+    cache = DynamicCache()
+    unfinished = torch.ones(B, dtype=torch.long)
+    with torch.no_grad():
+        for step in range(NEW):
+            if step == 0:
+                emb = torch.cat([inputs_embeds, (me[cfg.start_mel_token] + mp[0])[None, None].expand(B, 1, d)], 1)
+            else:
+                emb = (me[input_ids[:, -1]] + mp[attention_mask.shape[1] - P])[:, None]
+            o = gpt(inputs_embeds=emb, past_key_values=cache, attention_mask=attention_mask, use_cache=True, return_dict=True)
+            cache = o.past_key_values
+            scores = proc(input_ids, head(o.last_hidden_state[:, -1]).float().clone())
+            for wp in warpers:
+                scores = wp(input_ids, scores)
+            nxt = torch.multinomial(torch.softmax(scores, -1), num_samples=1).squeeze(1)
+            nxt = nxt * unfinished + cfg.stop_mel_token * (1 - unfinished)
+            input_ids = torch.cat([input_ids, nxt[:, None]], 1)
+            attention_mask = torch.cat([attention_mask, torch.ones(B, 1, dtype=torch.long)], 1)
+            unfinished = unfinished & (nxt != cfg.stop_mel_token).long()
+    out["sample_codes"] = input_ids[:, P + 1:].numpy()
+    torch.manual_seed(SEED)
+    noise = torch.stack([torch.empty(B, cfg.number_mel_codes).exponential_(1) for _ in range(NEW)])
+    out["sample_noise"] = noise.numpy()
+    out["sample_params"] = np.array([TEMP, TOPK, TOPP], dtype=np.float64)
+    chk = og.generate_sample(tw, cfg, conds, text, NEW, noise, 10.0, TEMP, TOPK, TOPP)
+    assert np.array_equal(chk.numpy(), out["sample_codes"][:, :chk.shape[1]]), "explicit-noise restatement != HF multinomial sampling"
     # ---- latent pass (no mask, causal): B=2, L=7, M=9 ----
     B2, L2, M2 = 2, 7, 9
     lat = torch.from_numpy(synth.uniform("golden/gpt/lat", (B2, cfg.cond_latents, d), 0.5))

@@ -275,3 +275,52 @@ def test_greedy_wide_mlp_k_split_vs_oracle(device):
     codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=14, repetition_penalty=10.0)
     ref = og.generate_greedy(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, 14, 10.0)
     assert np.array_equal(codes.cpu().numpy(), ref.numpy())
+
+
+def test_sampled_codes_bit_exact_vs_hf_golden(device, golden_dir):
+    """do_sample=True (HF warpers + torch.multinomial): fed the Exp(1) draws the golden run consumed, the HIP sampler must
+    return HF's tokens exactly -- eager and through the replayed graph."""
+    g, cfg, w, uv = _tiny(golden_dir, device)
+    B, L = g["greedy_text"].shape
+    NEW = g["sample_codes"].shape[1]
+    temp, top_k, top_p = g["sample_params"]
+    conds = torch.from_numpy(synth.uniform("golden/gpt/conds", (B, cfg.cond_latents + 2, cfg.model_dim), 0.5)).to(device)
+    text = torch.from_numpy(g["greedy_text"])
+    fake, emb, mask = uv.prepare_gpt_inputs(conds, text)
+    noise = torch.from_numpy(g["sample_noise"])
+    for graph in (False, True):
+        out = uv.generate(fake, max_new_tokens=NEW, stop_tokens=[cfg.stop_mel_token], attention_mask=mask, tts_embeddings=emb,
+                          repetition_penalty=10.0, use_graph=graph, do_sample=True, temperature=float(temp), top_k=int(top_k),
+                          top_p=float(top_p), exp_noise=noise)
+        assert np.array_equal(out[:, fake.shape[1]:].cpu().numpy(), g["sample_codes"]), f"graph={graph}"
+
+
+@pytest.mark.parametrize("case", [("hf", 0.8, 30, 0.8), ("hf", 1.3, 5, 0.5), ("hf", 0.7, 50, 1.0), ("hf", 1.0, 0, 1.0), ("accel", 0.8, 0, 1.0)])
+def test_sampling_modes_vs_oracle(device, case):
+    """Both samplers (HF multinomial with warpers, the accel engine's Gumbel-max Sampler) on a ragged batch of 6 against the
+    CPU oracle with the same Exp(1) draws; also through inference_speech with a seeded generator."""
+    from indextts_amd.gpt import UnifiedVoice
+    from oracle import gpt as og
+    sampler, temp, top_k, top_p = case
+    cfg = GPTConfig.tiny()
+    w = weights.synth_gpt_weights(cfg, tag="t/gpt/samp")
+    uv = UnifiedVoice(w, cfg, device=device)
+    tw = {k: torch.from_numpy(v) for k, v in w.items()}
+    B, L, NEW = 6, 9, 14
+    lat = torch.from_numpy(synth.uniform("t/gpt/samp/lat", (B, cfg.cond_latents, cfg.model_dim), 0.5))
+    emo = torch.from_numpy(synth.uniform("t/gpt/samp/emo", (B, cfg.model_dim), 0.3))
+    text = torch.from_numpy(synth.integers("t/gpt/samp/text", (B, L), 2, cfg.number_text_tokens))
+    text[2, 6:] = cfg.stop_text_token
+    text[5, 3:] = cfg.stop_text_token
+    gen = torch.Generator().manual_seed(99)
+    noise = torch.stack([torch.empty(B, cfg.number_mel_codes).exponential_(1, generator=gen) for _ in range(NEW)])
+    ref = og.generate_sample(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, NEW, noise, 10.0, temp, top_k, top_p,
+                             accel_sampler=(sampler == "accel"))
+    codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, repetition_penalty=10.0, do_sample=True,
+                                   temperature=temp, top_k=top_k, top_p=top_p, sampler=sampler, exp_noise=noise)
+    assert np.array_equal(codes.cpu().numpy(), ref.numpy())
+    # the draws can also come from a seeded generator: same seed, same order of exponential_() calls, same tokens
+    codes2, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, repetition_penalty=10.0, do_sample=True,
+                                    temperature=temp, top_k=top_k, top_p=top_p, sampler=sampler,
+                                    generator=torch.Generator().manual_seed(99))
+    assert np.array_equal(codes2.cpu().numpy(), ref.numpy())

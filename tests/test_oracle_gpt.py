@@ -77,3 +77,31 @@ def test_eos_bookkeeping():
         if len(hits):
             assert (row[hits[0]:] == cfg.stop_mel_token).all()
     assert codes.shape[1] <= 40
+
+
+def test_multinomial_sampling_matches_hf_golden(golden_dir):
+    """do_sample=True, num_beams=1: the golden codes come from HF's own warpers + torch.multinomial under a fixed seed; the
+    fixture also holds the Exp(1) draws multinomial consumed, so the oracle's argmax(probs / q) restatement must reproduce
+    the tokens exactly."""
+    g = np.load(os.path.join(golden_dir, "gpt.npz"))
+    cfg = GPTConfig.tiny()
+    tw = {k: torch.from_numpy(v) for k, v in weights.synth_gpt_weights(cfg, tag="golden/gpt").items()}
+    B = g["greedy_text"].shape[0]
+    conds = torch.from_numpy(synth.uniform("golden/gpt/conds", (B, cfg.cond_latents + 2, cfg.model_dim), 0.5))
+    text = torch.from_numpy(g["greedy_text"])
+    temp, top_k, top_p = g["sample_params"]
+    noise = torch.from_numpy(g["sample_noise"])
+    codes = og.generate_sample(tw, cfg, conds, text, g["sample_codes"].shape[1], noise, 10.0, float(temp), int(top_k), float(top_p))
+    assert np.array_equal(codes.numpy(), g["sample_codes"][:, :codes.shape[1]])
+    assert not np.array_equal(g["sample_codes"], g["greedy_codes"])        # the fixture actually samples
+
+
+def test_warp_scores_edge_cases():
+    """top-k keeps ties at the threshold; top-p never removes the largest; disabled filters are identities."""
+    s = torch.tensor([[1.0, 3.0, 3.0, 2.0, -1.0, 0.5]])
+    w = og.warp_scores(s.clone(), 1.0, 2, 1.0)
+    assert torch.isinf(w[0, [0, 3, 4, 5]]).all() and (w[0, [1, 2]] == 3.0).all()
+    w = og.warp_scores(s.clone(), 1.0, 0, 1e-6)
+    assert torch.isfinite(w).sum() >= 1 and torch.isfinite(w[0, 1:3]).any()
+    assert torch.equal(og.warp_scores(s.clone(), 1.0, 0, 1.0), s)
+    assert torch.allclose(og.warp_scores(s.clone(), 0.5, 0, 1.0), s / 0.5)

@@ -74,3 +74,13 @@ def test_infer_return_contract(device, tmp_path):
         tts.infer(cond, seg[0], None, stream_return=True, return_audio=True)
     with pytest.raises(NotImplementedError):
         tts.infer("examples/voice_01.wav", seg[0], None)
+    with pytest.raises(NotImplementedError):
+        tts.infer(cond, seg[0], None, num_beams=3, max_mel_tokens=16)
+    # the reference's sampling kwargs (num_beams=1): seeded draws make the run reproducible, and it differs from greedy
+    torch.manual_seed(7)       # the CFM noise comes from the global RNG (reference: torch.randn in flow_matching.py:62)
+    a = tts.infer(cond, seg[0], None, max_mel_tokens=16, do_sample=True, top_p=0.8, top_k=30, temperature=0.8, num_beams=1,
+                  generator=torch.Generator().manual_seed(5))
+    torch.manual_seed(7)
+    b = tts.infer(cond, seg[0], None, max_mel_tokens=16, do_sample=True, top_p=0.8, top_k=30, temperature=0.8, num_beams=1,
+                  generator=torch.Generator().manual_seed(5))
+    assert a[0] == 22050 and np.array_equal(a[1], b[1])
