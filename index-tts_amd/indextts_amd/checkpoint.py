@@ -1,6 +1,7 @@
 """Importer for the reference's real checkpoints (SURVEY.md §5 "Checkpoint / resume", §8f rank 4).
 
-Layouts read (none of these files ships offline; this code path is exercised only where they exist):
+Layouts read (none of these files ships offline; tests/test_checkpoint_cpu.py writes files in these layouts from the
+synthetic weights and checks the round trip, torch weight_norm pairs included):
   gpt.pth                 torch.load(...)['model'] or the dict itself   (utils/checkpoint.py:25-36)
   s2mel.pth               state['net'][{'cfm','length_regulator','gpt_layer'}] with 'module.' stripped (commons.py:588-621);
                           weight-norm pairs (weight_g, weight_v) are folded here: w = g * v / ||v||

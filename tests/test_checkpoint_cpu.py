@@ -1,0 +1,66 @@
+"""CPU: the real-checkpoint importer on files written in the reference's on-disk layouts
+(gpt.pth ['model'], s2mel.pth ['net'][...] with 'module.' prefixes, bigvgan_generator.pt ['generator'], weight-norm pairs
+weight_g / weight_v as torch.nn.utils.weight_norm stores them) round-trips to the state dicts the HIP contexts consume."""
+import os
+
+import numpy as np
+import torch
+
+from indextts_amd import weights
+from indextts_amd.checkpoint import fold_weight_norm, load_reference_checkpoints
+from indextts_amd.config import PipelineConfig
+
+
+def _split_weight_norm(sd, pick):
+    """w -> (weight_g, weight_v) with v an arbitrary positive rescale of w per dim-0 slice (what weight_norm(dim=0) stores)."""
+    out = {}
+    for i, (k, v) in enumerate(sd.items()):
+        t = torch.from_numpy(np.asarray(v)).clone()
+        if pick(k, t):
+            scale = 0.5 + torch.arange(t.shape[0], dtype=torch.float32).reshape(-1, *([1] * (t.dim() - 1))) % 3
+            wv = t * scale
+            out[k[: -len("weight")] + "weight_g"] = t.reshape(t.shape[0], -1).norm(dim=1).reshape(-1, *([1] * (t.dim() - 1)))
+            out[k[: -len("weight")] + "weight_v"] = wv
+        else:
+            out[k] = t
+    return out
+
+
+def test_reference_checkpoint_layouts_round_trip(tmp_path):
+    from safetensors.torch import save_file
+    cfg = PipelineConfig.tiny()
+    wg = weights.synth_gpt_weights(cfg.gpt, tag="t/ckpt/gpt")
+    ws = weights.synth_s2mel_weights(cfg.s2mel, tag="t/ckpt/s2mel")
+    wv = weights.synth_bigvgan_weights(cfg.bigvgan, tag="t/ckpt/voc")
+    torch.save({"model": {k: torch.from_numpy(v) for k, v in wg.items()}}, tmp_path / "gpt.pth")
+    net = {"cfm": {}, "length_regulator": {}, "gpt_layer": {}}
+    codec = {}
+    for k, v in ws.items():
+        head, rest = k.split(".", 1)
+        if head == "semantic_codec":
+            codec[rest] = torch.from_numpy(v).clone()
+        elif head in net:
+            net[head][rest] = v
+    conv3 = lambda k, t: k.endswith(".weight") and t.dim() == 3
+    net = {sub: {"module." + k: v for k, v in _split_weight_norm(sd, lambda k, t: conv3(k, t) and "wavenet" in k).items()}
+           for sub, sd in net.items()}
+    assert any(k.endswith("weight_g") for k in net["cfm"]), "fixture should contain weight-normed WaveNet layers"
+    torch.save({"net": net}, tmp_path / "s2mel.pth")
+    save_file(codec, str(tmp_path / "semantic_codec.safetensors"))
+    torch.save({"generator": _split_weight_norm(wv, conv3)}, tmp_path / "bigvgan_generator.pt")
+
+    gpt, s2mel, voc = load_reference_checkpoints(str(tmp_path))
+    for got, want, name in ((gpt, wg, "gpt"), (s2mel, ws, "s2mel"), (voc, wv, "bigvgan")):
+        assert set(got) == set(want), (name, sorted(set(got) ^ set(want))[:5])
+        for k in want:
+            np.testing.assert_allclose(got[k].numpy(), np.asarray(want[k]), rtol=2e-6, atol=1e-7, err_msg=f"{name}:{k}")
+
+
+def test_fold_weight_norm_matches_torch():
+    conv = torch.nn.utils.weight_norm(torch.nn.Conv1d(6, 10, 5))
+    convt = torch.nn.utils.weight_norm(torch.nn.ConvTranspose1d(6, 4, 8, stride=4))
+    for m in (conv, convt):
+        sd = {k: v.detach() for k, v in m.state_dict().items()}
+        assert any(k.endswith("weight_g") for k in sd)
+        folded = fold_weight_norm(sd)
+        assert torch.allclose(folded["weight"], m.weight.detach(), atol=1e-6)
