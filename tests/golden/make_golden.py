@@ -351,6 +351,31 @@ def make_gpt():
     print("wrote gpt.npz", {k: v.shape for k, v in out.items()}, "codes", out["greedy_codes"].tolist())
 
 
+def make_segments():
+    """Segment-splitter fixtures from the reference's TextTokenizer.split_segments_by_token (front.py:345-422): random token
+    streams over a small SentencePiece-like vocabulary (words, commas, dashes, apostrophes, sentence punctuation)."""
+    import json
+    import random
+    import warnings
+    from indextts.utils.front import TextTokenizer
+    vocab = ["▁the", "▁a", "ing", "▁in", "dex", "▁tts", "s", "▁to", "▁of", "▁mi", "▁wave", "front", "▁x", "y", "z", "▁go", "od",
+             ",", "▁,", "-", "'", "▁'", ".", "!", "?", "▁.", "▁?", "▁..."]
+    weights_ = [6] * 17 + [3, 2, 2, 2, 1, 4, 2, 2, 2, 1, 1]
+    rng = random.Random(20240611)
+    cases = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for n in [0, 1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 200] * 6:
+            toks = rng.choices(vocab, weights=weights_, k=n)
+            for limit, quick in ((120, 0), (20, 0), (8, 0), (30, 25), (12, 40)):
+                out = TextTokenizer.split_segments_by_token(list(toks), TextTokenizer.punctuation_marks_tokens, limit, quick)
+                cases.append({"tokens": toks, "limit": limit, "quick": quick, "segments": out})
+    path = os.path.join(HERE, "segments.json")
+    with open(path, "w", encoding="utf-8") as f:
+        json.dump({"punctuation": TextTokenizer.punctuation_marks_tokens, "cases": cases}, f, ensure_ascii=False)
+    print("wrote segments.json", len(cases), "cases")
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     torch.manual_seed(0)
@@ -362,3 +387,6 @@ if __name__ == "__main__":
             make_vocoder()
         if which in ("s2mel", "all") and "make_s2mel" in globals():
             globals()["make_s2mel"](Munch)
+    if which in ("segments", "all"):
+        _install_placeholders()
+        make_segments()
