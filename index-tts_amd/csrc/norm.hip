@@ -162,6 +162,38 @@ __global__ __launch_bounds__(256) void rows_norm_kernel(const RowsNormArgs p) {
   for (int i = 0; i < nper; ++i) { const int e = tid + (i << 8); if (e < d) put(e, v[i]); }
 }
 
+// adaLN-RMSNorm of the DiT (d = 512) straight to split-bf16 planes: one 128-lane half-workgroup per row, 16-byte loads,
+// 8-byte plane stores (the four lanes of a 16-k chunk write 32 contiguous bytes; rows of a workgroup are adjacent).
+// Same arithmetic as the generic kernel's NORM_ADA_RMS branch (sum of squares in a different order).
+__global__ __launch_bounds__(256) void ada_rms_planes512_kernel(const RowsNormArgs p) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, half = tid >> 7, t = tid & 127;
+  const int m = blockIdx.x * 2 + half;
+  const bool ok = m < p.M;
+  const f32x4 x = ok ? *reinterpret_cast<const f32x4*>(p.x_in + (size_t)m * p.ld_in + 4 * t) : f32x4{0.f, 0.f, 0.f, 0.f};
+  float ss = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  const float r = rsqrtf((red[2 * half] + red[2 * half + 1]) * (1.0f / 512.0f) + p.eps);
+  if (!ok) return;
+  const int b = p.rows_per_batch > 0 ? m / p.rows_per_batch : 0;
+  const f32x4 g = *reinterpret_cast<const f32x4*>(p.g1 + 4 * t);
+  f32x4 o = {x[0] * r * g[0], x[1] * r * g[1], x[2] * r * g[2], x[3] * r * g[3]};
+  if (p.mod_a) {
+    const f32x4 wm = *reinterpret_cast<const f32x4*>(p.mod_a + (size_t)b * p.ld_mod + 4 * t);
+    const f32x4 bm = *reinterpret_cast<const f32x4*>(p.mod_b + (size_t)b * p.ld_mod + 4 * t);
+    o = f32x4{wm[0] * o[0] + bm[0], wm[1] * o[1] + bm[1], wm[2] * o[2] + bm[2], wm[3] * o[3] + bm[3]};
+  }
+  idx_bf16x4 hi, lo;
+  split_bf16_x4(o, hi, lo);
+  __bf16* y_hi = static_cast<__bf16*>(p.y_planes);
+  const size_t off = plane_index(m, 4 * t, p.M);
+  *reinterpret_cast<idx_bf16x4*>(y_hi + off) = hi;
+  *reinterpret_cast<idx_bf16x4*>(y_hi + plane_elems(p.M, 512) + off) = lo;
+}
+
 int rows_norm_forward(const RowsNormArgs& a, hipStream_t stream) {
   if (a.M == 0) return 0;
   IDX_CHECK(a.M > 0 && a.d > 0 && a.d <= 256 * NORM_MAX_PER_THREAD, "rows_norm shape");
@@ -171,8 +203,15 @@ int rows_norm_forward(const RowsNormArgs& a, hipStream_t stream) {
   if (a.mode == NORM_ADA_RMS) IDX_CHECK(a.g1 && (!a.mod_a == !a.mod_b), "RMSNorm needs a weight (and both or no modulation vectors)");
   if (a.mode == NORM_MOD_LN) IDX_CHECK(a.mod_a && a.mod_b, "modulated LN needs shift and scale");
   if (a.in_frag || a.y_frag) IDX_CHECK((a.mode == NORM_LN || a.mode == NORM_LN_LN) && a.d % 16 == 0 && a.in_rows_per_batch == 0, "fragment-image I/O: LayerNorm modes, d % 16 == 0");
-  const double bytes = 4.0 * a.M * (double)a.d * (1.0 + a.num_partials + (a.x_out ? 1 : 0) + (a.y ? 1 : 0));
+  const double bytes = 4.0 * a.M * (double)a.d * (1.0 + a.num_partials + (a.x_out ? 1 : 0) + (a.y ? 1 : 0) + (a.y_planes ? 1 : 0));
   ProfScope prof(PROF_ROWS_NORM, stream, 0.0, bytes);
+  if (a.mode == NORM_ADA_RMS && a.d == 512 && a.y_planes && !a.y && a.x_in && !a.num_partials && !a.add_bias && !a.x_out && !a.in_frag &&
+      a.in_rows_per_batch == 0 && (a.ld_in & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.x_in) | reinterpret_cast<uintptr_t>(a.g1) | reinterpret_cast<uintptr_t>(a.mod_a) |
+                               reinterpret_cast<uintptr_t>(a.mod_b)) & 15) == 0 && (a.ld_mod & 3) == 0) {
+    hipLaunchKernelGGL(ada_rms_planes512_kernel, dim3((a.M + 1) / 2), dim3(256), 0, stream, a);
+    IDX_LAUNCH_CHECK();
+    return 0;
+  }
   const int nper = (a.d + 255) / 256;
   if (nper <= 2) hipLaunchKernelGGL(rows_norm_kernel<2>, dim3(a.M), dim3(256), 0, stream, a);
   else if (nper <= 5) hipLaunchKernelGGL(rows_norm_kernel<5>, dim3(a.M), dim3(256), 0, stream, a);

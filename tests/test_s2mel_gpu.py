@@ -151,7 +151,7 @@ def test_cfm_long_batch_dma_gemm_chain_vs_oracle(device):
     import dataclasses
     from indextts_amd.s2mel import S2Mel
     from oracle import s2mel as osm
-    cfg = dataclasses.replace(S2MelConfig.tiny(), hidden_dim=256, num_heads=4, depth=3, wn_hidden=256, wn_layers=2, block_size=1024)
+    cfg = dataclasses.replace(S2MelConfig.tiny(), hidden_dim=512, num_heads=8, depth=3, wn_hidden=512, wn_layers=2, block_size=1024)
     w = weights.synth_s2mel_weights(cfg, tag="t/s2mel/chain")
     sm = S2Mel(w, cfg, device=device, max_frames=1024)
     tw = {k: torch.from_numpy(v) for k, v in w.items()}
