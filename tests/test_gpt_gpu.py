@@ -324,3 +324,32 @@ def test_sampling_modes_vs_oracle(device, case):
                                     temperature=temp, top_k=top_k, top_p=top_p, sampler=sampler,
                                     generator=torch.Generator().manual_seed(99))
     assert np.array_equal(codes2.cpu().numpy(), ref.numpy())
+
+
+def test_full_size_greedy_and_latent_vs_oracle(device):
+    """The real IndexTTS-2 GPT (1280 x 24 layers, 8194 codes): greedy codes of a ragged batch bit-exact against the fp32 CPU
+    oracle, and the latent pass within tolerance -- the decode kernels at their production shapes (folded LayerNorm at
+    d = 1280, K-split mlp.c_proj, 20 heads)."""
+    from indextts_amd.gpt import UnifiedVoice
+    from oracle import gpt as og
+    cfg = GPTConfig()
+    w = weights.synth_gpt_weights(cfg, tag="bench/gpt")
+    uv = UnifiedVoice(w, cfg, device=device)
+    tw = {k: torch.from_numpy(v) for k, v in w.items()}
+    B, L, NEW = 2, 10, 8
+    lat = torch.from_numpy(synth.uniform("t/gpt/full/lat", (B, cfg.cond_latents, cfg.model_dim), 0.5))
+    emo = torch.from_numpy(synth.uniform("t/gpt/full/emo", (B, cfg.model_dim), 0.3))
+    text = torch.from_numpy(synth.integers("t/gpt/full/text", (B, L), 2, cfg.number_text_tokens))
+    text[1, 6:] = cfg.stop_text_token
+    codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, repetition_penalty=10.0)
+    with torch.no_grad():
+        ref = og.generate_greedy(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, NEW, 10.0)
+    assert np.array_equal(codes.cpu().numpy(), ref.numpy())
+    n = ref.shape[1]
+    lens = torch.tensor([n, n])
+    got = uv.forward(lat, text, torch.tensor([L, 6]), codes.cpu(), lens, emo_vec=emo).cpu()
+    # the batched latent pass masks the text padding so that every row equals its own B = 1 call (what infer_v2.py:816 runs)
+    for b, tl in enumerate((L, 6)):
+        with torch.no_grad():
+            want = og.latent_forward(tw, cfg, lat[b:b + 1], text[b:b + 1, :tl], ref[b:b + 1], emo[b:b + 1])
+        assert (got[b:b + 1] - want).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item()), b
