@@ -87,6 +87,12 @@ size_t idxtts_bigvgan_workspace_bytes(const idxtts_ctx* ctx, int B, int Tm);
  * is skipped (tests compare the pre-clamp waveform so saturation cannot hide an error). */
 int idxtts_bigvgan_fwd(idxtts_ctx* ctx, const float* mel, float* wav, int B, int Tm, void* workspace,
                        size_t workspace_bytes, int clamp, int stage_idx, float* stage_out, void* stream);
+/* Ragged batch: mel_lengths = device int32 [B], valid frames of each row (<= Tm; mel must be zero beyond them).  Row b of the
+ * result equals idxtts_bigvgan_fwd on mel[b, :, :mel_lengths[b]] alone -- every layer pads (zeros for the convolutions,
+ * replicate for the anti-alias filters) at the row's OWN end, as the reference's per-utterance call does (infer_v2.py:860);
+ * samples beyond mel_lengths[b] * prod(upsample_rates) are not meaningful. */
+int idxtts_bigvgan_fwd_ragged(idxtts_ctx* ctx, const float* mel, const int* mel_lengths, float* wav, int B, int Tm, void* workspace,
+                              size_t workspace_bytes, int clamp, void* stream);
 
 /* ---- token-major building blocks (also used stand-alone by the tests) ------------------------------
  * idxtts_linear: Y[M][N] = act(X[M][K] W^T + bias) (+ residual) on the fp32 matrix core.

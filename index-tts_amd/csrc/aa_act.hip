@@ -37,6 +37,8 @@ struct AAParams {
   const float* log_alpha;  // [C]
   const float* log_beta;   // [C]
   int C, T;
+  const int* lens;       // optional [B]: valid samples of row b = lens[b] * len_mul (<= T); the tail is written as zeros and the
+  int len_mul;           // replicate padding is applied at the row's OWN end, as a B = 1 call on the unpadded row would
 };
 
 __device__ __forceinline__ float snake(float u, float a, float inv_b) {
@@ -44,6 +46,9 @@ __device__ __forceinline__ float snake(float u, float a, float inv_b) {
   return u + inv_b * (s * s);
 }
 
+// RAGGED = false is the original single-length kernel (the hot path of equal-length batches); RAGGED = true adds the per-row
+// length handling of AAParams::lens.
+template <bool RAGGED>
 __global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
   __shared__ __attribute__((aligned(16))) float xs[AA_TILE + 2 * AA_XH];
   __shared__ __attribute__((aligned(16))) float ve[AA_TILE + 2 * AA_VH];
@@ -51,9 +56,10 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
 
   const int tid = threadIdx.x;
   const int c = blockIdx.y, b = blockIdx.z;
-  const int T = p.T;
+  const int Tstride = p.T;                                                     // row stride of the padded tensor
+  const int T = RAGGED ? min(p.T, p.lens[b] * p.len_mul) : p.T;               // this row's own length
   const int t0 = blockIdx.x * AA_TILE;
-  const size_t row = ((size_t)b * p.C + c) * T;
+  const size_t row = ((size_t)b * p.C + c) * Tstride;
   const float* __restrict__ x = p.x + row;
 
   // filters and per-channel constants (wave-uniform -> scalar registers)
@@ -68,6 +74,11 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
   const float a = expf(p.log_alpha[c]);
   const float inv_b = 1.0f / (expf(p.log_beta[c]) + 1e-9f);
 
+  if (RAGGED && t0 >= T) {       // tile entirely in the padding of a shorter row: zeros
+    float* __restrict__ yz = p.y + row;
+    for (int i = tid; i < AA_TILE && t0 + i < Tstride; i += 256) yz[t0 + i] = 0.0f;
+    return;
+  }
   // ---- phase 1: x tile with replicate (clamped) halo ----
   for (int i = tid; i < AA_TILE + 2 * AA_XH; i += 256) {
     int t = t0 - AA_XH + i;
@@ -128,7 +139,14 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
 
   // ---- phase 3: polyphase down-sample, 4 outputs per thread ----
   const int t = t0 + 4 * tid;
-  if (t >= T) return;
+  if (t >= Tstride) return;
+  if (RAGGED && t >= T) {        // padding of a shorter row inside a partly valid tile
+    float* __restrict__ yz = p.y + row;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (t + i < Tstride) yz[t + i] = 0.0f;
+    return;
+  }
   float ew[12], ow[12];
   {
     const f32x4 e0 = *reinterpret_cast<const f32x4*>(&ve[4 * tid]);
@@ -156,25 +174,26 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
     out[i] = acc;
   }
   float* __restrict__ y = p.y + row;
-  if ((T & 3) == 0) {
+  if ((Tstride & 3) == 0 && (!RAGGED || t + 3 < T)) {
     *reinterpret_cast<f32x4*>(&y[t]) = f32x4{out[0], out[1], out[2], out[3]};
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (t + i < T) y[t + i] = out[i];
+      if (t + i < Tstride) y[t + i] = t + i < T ? out[i] : 0.0f;
   }
 }
 
 int aa_act_forward(float* y, const float* x, const float* up_f, const float* down_f, const float* log_alpha,
-                   const float* log_beta, int B, int C, int T, hipStream_t stream) {
+                   const float* log_beta, int B, int C, int T, hipStream_t stream, const int* lens, int len_mul) {
   if (B == 0 || C == 0 || T == 0) return 0;   // reference: seq_len == 0 -> no-op (.cu:193)
   IDX_CHECK(y && x && up_f && down_f && log_alpha && log_beta, "null pointer");
   IDX_CHECK(y != x, "aa_act is not in-place safe (tile halos)");
   IDX_CHECK(C <= 65535 && B <= 65535, "grid y/z limit");
-  AAParams p{x, y, up_f, down_f, log_alpha, log_beta, C, T};
+  AAParams p{x, y, up_f, down_f, log_alpha, log_beta, C, T, lens, len_mul};
   dim3 grid(cdiv(T, AA_TILE), C, B);
   ProfScope prof(PROF_AA_ACT, stream, 0.0, 8.0 * B * C * (double)T);   // one read + one write per element
-  hipLaunchKernelGGL(aa_act_kernel, grid, dim3(256), 0, stream, p);
+  if (lens) hipLaunchKernelGGL(aa_act_kernel<true>, grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(aa_act_kernel<false>, grid, dim3(256), 0, stream, p);
   IDX_LAUNCH_CHECK();
   return 0;
 }

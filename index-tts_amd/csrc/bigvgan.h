@@ -30,7 +30,7 @@ struct BigVGANModel : ModelBase {
   size_t max_elems(int B, int Tm) const;
   size_t workspace_bytes(int B, int Tm) const;
   int forward(const float* mel, float* wav, int B, int Tm, void* workspace, size_t workspace_bytes, int clamp,
-              int stage_idx, float* stage_out, hipStream_t stream);
+              int stage_idx, float* stage_out, hipStream_t stream, const int* lens = nullptr);
 };
 
 }  // namespace idxtts

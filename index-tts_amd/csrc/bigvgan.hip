@@ -17,7 +17,7 @@
 namespace idxtts {
 
 int aa_act_forward(float* y, const float* x, const float* up_f, const float* down_f, const float* log_alpha,
-                   const float* log_beta, int B, int C, int T, hipStream_t stream);
+                   const float* log_beta, int B, int C, int T, hipStream_t stream, const int* lens = nullptr, int len_mul = 1);
 int conv_post_forward(float* y, const float* x, const float* w, int B, int C, int T, int clamp, hipStream_t stream);
 
 // kaiser-sinc low-pass, cutoff 0.25, half-width 0.3, 12 taps (filter.py:30-62), in double.
@@ -188,8 +188,10 @@ size_t BigVGANModel::workspace_bytes(int B, int Tm) const {
   return 6 * per;
 }
 
+// lens: optional device int32 [B], valid mel frames per row (<= Tm; the mel must be zero beyond them).  Every layer then keeps
+// a shorter row's tail at zero and pads / replicates at that row's own end, so row b equals the B = 1 call on mel[b, :, :lens[b]].
 int BigVGANModel::forward(const float* mel, float* wav, int B, int Tm, void* workspace, size_t workspace_bytes_in,
-                          int clamp, int stage_idx, float* stage_out, hipStream_t stream) {
+                          int clamp, int stage_idx, float* stage_out, hipStream_t stream, const int* lens) {
   IDX_CHECK(mel && wav, "null pointer");
   if (B == 0 || Tm == 0) return 0;
   IDX_CHECK(workspace && workspace_bytes_in >= workspace_bytes(B, Tm), "workspace too small");
@@ -205,31 +207,33 @@ int BigVGANModel::forward(const float* mel, float* wav, int B, int Tm, void* wor
   ConvArgs a;
   a.B = B;
   // conv_pre: Conv1d(num_mels -> C0, k7, pad 3)   bigvgan.py:362
-  a.x = mel; a.y = P; a.T = Tm; a.dil = 1; a.pad_left = 3;
+  a.x = mel; a.y = P; a.T = Tm; a.dil = 1; a.pad_left = 3; a.lens = lens; a.len_mul_out = 1;
   if (conv1d_forward(conv_pre, a, stream)) return 1;
 
   int T = Tm;
+  int mul = 1;          // samples per mel frame at the current stage
   for (int i = 0; i < cfg.num_upsamples; ++i) {
     const int u = cfg.upsample_rates[i];
     const int C = stage_channels(i + 1);
     // ConvTranspose1d as a 3-tap conv over x[s-1..s+1] with interleaved store   bigvgan.py:367
     ConvArgs up;
-    up.B = B; up.x = P; up.y = X0; up.T = T; up.dil = 1; up.pad_left = 1;
+    up.B = B; up.x = P; up.y = X0; up.T = T; up.dil = 1; up.pad_left = 1; up.lens = lens; up.len_mul_out = mul * u;
     if (conv1d_forward(ups[i], up, stream)) return 1;
     T *= u;
+    mul *= u;
     for (int j = 0; j < cfg.num_kernels; ++j) {
       AmpBlock& blk = blocks[i * cfg.num_kernels + j];
       const int k = blk.kernel;
       for (int l = 0; l < 3; ++l) {
         const float* src = (l == 0) ? X0 : R;
         const int d = blk.dil[l];
-        if (aa_act_forward(ACT, src, up_filter, down_filter, blk.alpha[2 * l], blk.beta[2 * l], B, C, T, stream)) return 1;
+        if (aa_act_forward(ACT, src, up_filter, down_filter, blk.alpha[2 * l], blk.beta[2 * l], B, C, T, stream, lens, mul)) return 1;
         ConvArgs c1;
-        c1.B = B; c1.x = ACT; c1.y = T1; c1.T = T; c1.dil = d; c1.pad_left = (k * d - d) / 2;
+        c1.B = B; c1.x = ACT; c1.y = T1; c1.T = T; c1.dil = d; c1.pad_left = (k * d - d) / 2; c1.lens = lens; c1.len_mul_out = mul;
         if (conv1d_forward(blk.convs1[l], c1, stream)) return 1;
-        if (aa_act_forward(ACT, T1, up_filter, down_filter, blk.alpha[2 * l + 1], blk.beta[2 * l + 1], B, C, T, stream)) return 1;
+        if (aa_act_forward(ACT, T1, up_filter, down_filter, blk.alpha[2 * l + 1], blk.beta[2 * l + 1], B, C, T, stream, lens, mul)) return 1;
         ConvArgs c2;
-        c2.B = B; c2.x = ACT; c2.T = T; c2.dil = 1; c2.pad_left = (k - 1) / 2; c2.res = src;
+        c2.B = B; c2.x = ACT; c2.T = T; c2.dil = 1; c2.pad_left = (k - 1) / 2; c2.res = src; c2.lens = lens; c2.len_mul_out = mul;
         if (l < 2) {
           c2.y = R;                       // x = xt + x            bigvgan.py:139
         } else {
@@ -245,7 +249,7 @@ int BigVGANModel::forward(const float* mel, float* wav, int B, int Tm, void* wor
     std::swap(P, XS);
   }
   const int cl = stage_channels(cfg.num_upsamples);
-  if (aa_act_forward(ACT, P, up_filter, down_filter, post_alpha, post_beta, B, cl, T, stream)) return 1;   // bigvgan.py:378
+  if (aa_act_forward(ACT, P, up_filter, down_filter, post_alpha, post_beta, B, cl, T, stream, lens, mul)) return 1;   // bigvgan.py:378
   if (conv_post_forward(wav, ACT, conv_post_w, B, cl, T, clamp, stream)) return 1;                        // bigvgan.py:379-384
   return 0;
 }

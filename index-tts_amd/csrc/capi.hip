@@ -21,7 +21,7 @@ int fail(const char* file, int line, const std::string& msg) {
 }
 
 int aa_act_forward(float* y, const float* x, const float* up_f, const float* down_f, const float* log_alpha,
-                   const float* log_beta, int B, int C, int T, hipStream_t stream);
+                   const float* log_beta, int B, int C, int T, hipStream_t stream, const int* lens = nullptr, int len_mul = 1);
 
 }  // namespace idxtts
 
@@ -184,6 +184,17 @@ int idxtts_bigvgan_fwd(idxtts_ctx* ctx, const float* mel, float* wav, int B, int
   IDX_CHECK(m, "not a BigVGAN context");
   IDX_CHECK(B >= 0 && Tm >= 0, "negative shape");
   return m->forward(mel, wav, B, Tm, workspace, workspace_bytes, clamp, stage_idx, stage_out, static_cast<hipStream_t>(stream));
+  API_END
+}
+
+int idxtts_bigvgan_fwd_ragged(idxtts_ctx* ctx, const float* mel, const int* mel_lengths, float* wav, int B, int Tm, void* workspace,
+                              size_t workspace_bytes, int clamp, void* stream) {
+  API_BEGIN
+  IDX_CHECK(ctx && ctx->finalized, "context not finalized");
+  auto* m = dynamic_cast<BigVGANModel*>(ctx->model.get());
+  IDX_CHECK(m, "not a BigVGAN context");
+  IDX_CHECK(B >= 0 && Tm >= 0 && mel_lengths, "shape / lengths");
+  return m->forward(mel, wav, B, Tm, workspace, workspace_bytes, clamp, 0, nullptr, static_cast<hipStream_t>(stream), mel_lengths);
   API_END
 }
 

@@ -44,6 +44,9 @@ struct ConvArgs {
   int pad_mode = PAD_ZERO;
   float scale = 1.0f;          // v = (acc + bias + res) * scale
   int accum = 0;               // y = accum ? y + v : v
+  // ragged batches: output samples t >= lens[b] * len_mul_out are written as 0 (a shorter row's tail stays zero, so the next
+  // layer's zero padding at that row's own end is what a B = 1 call would see)
+  const int* lens = nullptr; int len_mul_out = 1;
 };
 
 int conv1d_forward(const ConvWeights& w, const ConvArgs& a, hipStream_t stream);

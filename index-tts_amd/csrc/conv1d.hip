@@ -87,6 +87,7 @@ struct ConvKP {
   int ntiles_row, ntiles, nt8;
   float scale;
   int accum;
+  const int* lens; int len_mul_out;
 };
 
 template <int TM, int TN, int WGM, int WGN>
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvKP p) {
       const int co = m >> u_log2, ph = m & u_mask;
       const float bias = p.bias ? p.bias[co] : 0.0f;
       const size_t rowoff = ((size_t)b * Cout + co) * Tout + ph;
+      const size_t own_len = p.lens ? (size_t)p.lens[b] * p.len_mul_out : Tout;     // this row's valid output samples
 #pragma unroll
       for (int nt = 0; nt < TN; ++nt) {
         const int n = t0 + (wn * TN + nt) * 32 + j;
@@ -246,6 +248,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvKP p) {
         float v = acc[mt][nt][r] + bias;
         if (p.res) v += p.res[idx];
         v *= p.scale;
+        if (((size_t)n << u_log2) + ph >= own_len) v = 0.0f;
         if (p.accum) v += p.y[idx];
         p.y[idx] = v;
       }
@@ -272,7 +275,7 @@ static int launch_conv(const ConvWeights& w, const ConvArgs& a, hipStream_t stre
   p.ntiles_row = cdiv(a.T, BN);
   p.ntiles = p.ntiles_row * a.B;
   p.nt8 = cdiv(p.ntiles, 8);
-  p.scale = a.scale; p.accum = a.accum;
+  p.scale = a.scale; p.accum = a.accum; p.lens = a.lens; p.len_mul_out = a.len_mul_out;
   const int mblocks = cdiv(w.M, BM);
   const size_t lds = (size_t)(2 * NSUB * CONV_SUB + 2 * 16 * p.xs) * sizeof(float);
   const int64_t grid = (int64_t)8 * mblocks * p.nt8;

@@ -17,7 +17,7 @@ SYMBOLS = [
     "idxtts_version", "idxtts_last_error", "idxtts_aa_act_fwd",
     "idxtts_conv1d_create", "idxtts_conv1d_fwd", "idxtts_conv1d_destroy",
     "idxtts_ctx_load_tensor", "idxtts_ctx_finalize", "idxtts_ctx_destroy",
-    "idxtts_bigvgan_create", "idxtts_bigvgan_workspace_bytes", "idxtts_bigvgan_fwd",
+    "idxtts_bigvgan_create", "idxtts_bigvgan_workspace_bytes", "idxtts_bigvgan_fwd", "idxtts_bigvgan_fwd_ragged",
     "idxtts_profile_enable", "idxtts_profile_num_kernels", "idxtts_profile_kernel_name", "idxtts_profile_read",
     "idxtts_linear_create", "idxtts_linear_fwd", "idxtts_linear_destroy", "idxtts_attention_fwd", "idxtts_attention_bf16x3_fwd", "idxtts_layernorm_fwd",
     "idxtts_gpt_create", "idxtts_gpt_workspace_bytes", "idxtts_gpt_embed", "idxtts_gpt_generate", "idxtts_gpt_generate_sampled", "idxtts_gpt_latent",
@@ -81,6 +81,7 @@ def load() -> ctypes.CDLL:
     lib.idxtts_bigvgan_workspace_bytes.restype = c_size_t
     lib.idxtts_bigvgan_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_int, c_int,
                                        c_void_p, c_void_p]
+    lib.idxtts_bigvgan_fwd_ragged.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_int, c_void_p]
     c_long = ctypes.c_long
     lib.idxtts_linear_create.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_void_p)]
     lib.idxtts_linear_fwd.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]

@@ -174,17 +174,16 @@ class IndexTTS2:
         vc_target = mel[:, :, Tp:]                                                          # infer_v2.py:856
         t3 = tick()
         times["s2mel_time"] = t3 - t2
-        # vocoder: utterances of equal length go through together; others one by one, so that every conv sees the
-        # zero padding of its OWN sequence end exactly as the reference's B=1 call does (infer_v2.py:860)
+        # vocoder: one ragged batch; every layer pads at each row's OWN end (zeros for the convolutions, replicate for the
+        # anti-alias filters), exactly what the reference's B=1 call per utterance sees (infer_v2.py:860)
         wavs: List[Optional[torch.Tensor]] = [None] * B
         tl = target_lens.cpu().tolist()
-        for length in sorted(set(tl)):
-            rows = [b for b in range(B) if tl[b] == length]
-            m = vc_target[rows, :, :length].contiguous()
-            w = self.bigvgan(m.float())
-            w = torch.clamp(32767 * w, -32767.0, 32767.0)                                   # infer_v2.py:866
-            for i, b in enumerate(rows):
-                wavs[b] = w[i]
+        Tmax = max(tl)
+        w = self.bigvgan(vc_target[:, :, :Tmax].float().contiguous(), lengths=tl if len(set(tl)) > 1 else None)
+        w = torch.clamp(32767 * w, -32767.0, 32767.0)                                       # infer_v2.py:866
+        up = self.cfg.bigvgan.total_upsample
+        for b in range(B):
+            wavs[b] = w[b, :, : tl[b] * up].contiguous()
         t4 = tick()
         times["bigvgan_time"] = t4 - t3
         self.last_stage_times = times

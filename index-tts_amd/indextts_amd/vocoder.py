@@ -132,8 +132,10 @@ class BigVGAN:
     def workspace_bytes(self, B: int, Tm: int) -> int:
         return int(_lib.load().idxtts_bigvgan_workspace_bytes(self._h, B, Tm))
 
-    def forward(self, mel: torch.Tensor, clamp: bool = True, stage: int = 0):
-        """mel [B,num_mels,Tm] -> wav [B,1,Tm*256].  `stage` (1..6) additionally returns that stage's output."""
+    def forward(self, mel: torch.Tensor, clamp: bool = True, stage: int = 0, lengths=None):
+        """mel [B,num_mels,Tm] -> wav [B,1,Tm*256].  `stage` (1..6) additionally returns that stage's output.
+        lengths (optional, [B] ints <= Tm): a ragged batch -- row b equals the call on mel[b:b+1, :, :lengths[b]] alone
+        (valid samples: the first lengths[b] * 256); the mel is zeroed beyond each row's length here."""
         lib = _lib.load()
         mel = _require_gpu_f32(mel, "mel")
         if mel.dim() != 3 or mel.shape[1] != self.cfg.num_mels:
@@ -145,6 +147,17 @@ class BigVGAN:
         need = self.workspace_bytes(B, Tm)
         if self._ws is None or self._ws.numel() < need or self._ws.device != mel.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=mel.device)
+        if lengths is not None:
+            if stage:
+                raise ValueError("stage output is not available for ragged batches")
+            lens = torch.as_tensor(lengths, dtype=torch.int32).reshape(-1)
+            if lens.numel() != B or int(lens.min()) < 0 or int(lens.max()) > Tm:
+                raise ValueError("lengths must be [B] with 0 <= lengths[b] <= Tm")
+            lens_d = lens.to(mel.device)
+            mel = (mel * (torch.arange(Tm, device=mel.device)[None, None, :] < lens_d[:, None, None])).contiguous()
+            _lib.check(lib.idxtts_bigvgan_fwd_ragged(self._h, _lib.ptr(mel), _lib.ptr(lens_d), _lib.ptr(wav), B, Tm, _lib.ptr(self._ws),
+                                                     self._ws.numel(), int(clamp), _lib.current_stream()))
+            return wav
         stage_out = None
         if stage:
             T = Tm

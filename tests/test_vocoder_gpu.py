@@ -220,3 +220,21 @@ def test_bigvgan_full_size_properties(device):
     wav2 = voc(mel2)
     assert torch.equal(wav2[..., : 600 * 256], wav[..., : 600 * 256])
     assert not torch.equal(wav2[..., 760 * 256:], wav[..., 760 * 256:])
+
+
+def test_bigvgan_ragged_batch_equals_per_row_calls(device):
+    """A ragged batch (lengths 9, 23, 1, 16 of 23 mel frames) through idxtts_bigvgan_fwd_ragged: row b must equal the
+    vocoder run on that row's own mel alone -- zero padding of the convolutions and replicate padding of the anti-alias
+    filters both happen at the row's own end."""
+    from indextts_amd.vocoder import BigVGAN
+    cfg = BigVGANConfig.tiny(128)
+    w = weights.synth_bigvgan_weights(cfg, tag="t/bigvgan/ragged")
+    voc = BigVGAN(w, cfg)
+    lens = [9, 23, 1, 16]
+    mel = torch.from_numpy(weights.synth_mel("t/bigvgan/ragged/mel", len(lens), cfg.num_mels, max(lens))).to(device)
+    got = voc(mel, clamp=False, lengths=lens)
+    up = cfg.total_upsample
+    for b, n in enumerate(lens):
+        solo = voc(mel[b:b + 1, :, :n].contiguous(), clamp=False)
+        assert solo.shape[-1] == n * up
+        assert torch.allclose(got[b:b + 1, :, : n * up], solo, atol=1e-6 * TOL["m"]), (b, (got[b:b + 1, :, : n * up] - solo).abs().max().item())
