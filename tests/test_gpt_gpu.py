@@ -52,7 +52,8 @@ def test_gemm_tn_vs_torch(device, shape):
 
 
 @pytest.mark.parametrize("shape", [(256, 128, 32), (300, 1536, 512), (1000, 512, 864), (129, 80, 512), (640, 512, 1536), (513, 8194, 128),
-                                   (4100, 1536, 512), (5003, 80, 512), (4096, 320, 96)])   # >= 4096 rows: the 256-row tile kernel
+                                   (4100, 1536, 512), (5003, 80, 512), (4096, 320, 96),     # >= 4096 rows: the 256-row tile kernel
+                                   (16640, 1024, 512), (16500, 1280, 256)])                # 260 / 325 tiles: K-split tail tiles
 def test_gemm_split_bf16_vs_torch(device, shape):
     """Split-bf16 GEMM (3 bf16 MFMAs per product): relative error ~2^-16 per product, i.e. ~1e-5 of the row scale."""
     M, N, K = shape
