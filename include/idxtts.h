@@ -64,7 +64,13 @@ int idxtts_conv1d_destroy(idxtts_conv1d* conv);
 int idxtts_ctx_load_tensor(idxtts_ctx* ctx, const char* name, const float* data, const int64_t* shape, int ndim);
 /* Pack everything loaded so far into kernel layouts on the current device; fails if a tensor is missing. */
 int idxtts_ctx_finalize(idxtts_ctx* ctx);
+/* Read a staged tensor back (host fp32, `capacity` floats) before finalize: after idxtts_gpt_quantize_weights this is the
+ * exact model every kernel will run, under the reference's own keys (what a parity check feeds the reference / oracle). */
+int idxtts_ctx_get_tensor(idxtts_ctx* ctx, const char* name, float* host_out, size_t capacity);
 int idxtts_ctx_destroy(idxtts_ctx* ctx);
+/* OCP fp8 e4m3fn value of a code / nearest-even saturating code of a value (host helpers of the fp8 weight format). */
+float idxtts_fp8_e4m3_decode(unsigned char code);
+unsigned char idxtts_fp8_e4m3_encode(float v);
 
 /* ---- BigVGAN-v2 vocoder (reference: BigVGAN.forward, bigvgan.py:360-386) ------------------------- */
 typedef struct idxtts_bigvgan_config {
@@ -141,6 +147,16 @@ typedef struct idxtts_gpt_config {
 } idxtts_gpt_config;
 int idxtts_gpt_create(const idxtts_gpt_config* cfg, idxtts_ctx** out);
 /* Scratch for sequences of S tokens per row (prefill: P+1; latent pass: 34+L+2+M+2) and max_new_tokens of decode. */
+/* Compact storage of the GPT's linear weights (call between the last idxtts_ctx_load_tensor and idxtts_ctx_finalize).
+ * Replaces the reference's reduced-precision switch (`use_fp16` -> self.gpt.half(), infer_v2.py:109, 145-146) and is what
+ * BASELINE.json configs[4] names ("fp8 GPT GEMMs"): the decode step is bound by the weight stream, so the format decides
+ * the bytes per token; the arithmetic stays the fp32 MFMA.
+ *   format 0: fp32 (default, no-op)   1: bf16 (nearest-even)   2: fp8 e4m3fn with a power-of-two scale per output channel
+ * The staged tensors are rewritten IN PLACE into an ordinary fp32 GPT-2 state that the format holds exactly --
+ *   c_attn / c_fc: (ln.weight, ln.bias, W, b) -> (1, 0, Q(diag(ln.weight) W), ln.bias . W + b);   c_proj, mlp.c_proj, mel_head: Q(W)
+ * (mathematically the same network up to Q) -- and prefill, latent pass and decode are all packed from them, so the three
+ * passes run one model and idxtts_ctx_get_tensor returns exactly that model for the reference / oracle to run. */
+int idxtts_gpt_quantize_weights(idxtts_ctx* ctx, int format);
 size_t idxtts_gpt_workspace_bytes(const idxtts_ctx* ctx, int B, int S, int max_new_tokens);
 /* out[r] = text_emb[text_ids[r]] + text_pos[text_pos_idx[r]] + mel_emb[mel_ids[r]] + mel_pos[mel_pos_idx[r]] + extra[extra_idx[r]],
  * every term skipped where its index is < 0 (or its index array is NULL).  Index arrays are device int32 [rows].

@@ -154,10 +154,25 @@ int idxtts_ctx_finalize(idxtts_ctx* ctx) {
   API_END
 }
 
+int idxtts_ctx_get_tensor(idxtts_ctx* ctx, const char* name, float* host_out, size_t capacity) {
+  API_BEGIN
+  IDX_CHECK(ctx && name && host_out, "null pointer");
+  IDX_CHECK(!ctx->finalized, "staged tensors are released by finalize");
+  auto it = ctx->tensors.find(name);
+  if (it == ctx->tensors.end()) IDX_FAIL(std::string("no staged tensor '") + name + "'");
+  IDX_CHECK(capacity >= it->second.data.size(), "output buffer too small");
+  std::copy(it->second.data.begin(), it->second.data.end(), host_out);
+  return 0;
+  API_END
+}
+
 int idxtts_ctx_destroy(idxtts_ctx* ctx) {
   delete ctx;
   return 0;
 }
+
+float idxtts_fp8_e4m3_decode(unsigned char code) { return fp8_e4m3_decode(code); }
+unsigned char idxtts_fp8_e4m3_encode(float v) { return fp8_e4m3_encode(v); }
 
 int idxtts_bigvgan_create(const idxtts_bigvgan_config* cfg, idxtts_ctx** out) {
   API_BEGIN
@@ -288,6 +303,16 @@ int idxtts_gpt_create(const idxtts_gpt_config* cfg, idxtts_ctx** out) {
   ctx->model.reset(new GPTModel(*cfg));
   *out = ctx.release();
   return 0;
+  API_END
+}
+
+int idxtts_gpt_quantize_weights(idxtts_ctx* ctx, int format) {
+  API_BEGIN
+  IDX_CHECK(ctx, "null ctx");
+  IDX_CHECK(!ctx->finalized, "quantise before idxtts_ctx_finalize");
+  auto* m = dynamic_cast<GPTModel*>(ctx->model.get());
+  IDX_CHECK(m, "not a GPT context");
+  return m->quantize_weights(ctx->tensors, format);
   API_END
 }
 

@@ -28,6 +28,14 @@ struct DeviceArena {   // owns hipMalloc'd blocks of a context
     *out = static_cast<float*>(d);
     return 0;
   }
+  int upload_bytes(const void* host, size_t bytes, void** out) {
+    void* d = nullptr;
+    IDX_HIP(hipMalloc(&d, bytes ? bytes : 1));
+    blocks.push_back(d);
+    if (bytes) IDX_HIP(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice));
+    *out = d;
+    return 0;
+  }
 };
 
 struct ModelBase {

@@ -19,7 +19,11 @@
 //   * the K-slices of the 16 waves of a workgroup are reduced through LDS in a fixed order; bias / colsum / residual
 //     operands of the epilogue are fetched at kernel entry.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
 
 #include "gemv16.h"
 #include "prof.h"
@@ -53,9 +57,122 @@ void pack_gemv16_nk(float* dst, const float* w_nk, int N, int K) {
     }
 }
 
+// ---- compact weight formats (gemv16.h) ----
+float fp8_e4m3_decode(unsigned char code) {
+  const int e = (code >> 3) & 15, m = code & 7;
+  float v;
+  if (e == 15 && m == 7) v = NAN;
+  else if (e == 0) v = ldexpf((float)m, -9);                 // m/8 * 2^-6
+  else v = ldexpf(8.0f + (float)m, e - 10);                  // (1 + m/8) * 2^(e-7)
+  return (code & 0x80) ? -v : v;
+}
+
+unsigned char fp8_e4m3_encode(float v) {
+  const unsigned char sign = std::signbit(v) ? 0x80 : 0;
+  const float a = std::fabs(v);
+  if (!(a < 448.0f)) return sign | 126;                      // saturate (NaN too: quantize_matrix never feeds one)
+  if (a < 0.015625f) return sign | (unsigned char)nearbyintf(a * 512.0f);   // subnormal grid 2^-9 (8 -> the smallest normal)
+  uint32_t u; memcpy(&u, &a, 4);
+  u += 0x7ffffu + ((u >> 20) & 1u);                          // nearest-even on the 3 kept mantissa bits
+  const int c = (int)(u >> 20) - ((127 - 7) << 3);
+  return sign | (unsigned char)std::min(c, 126);
+}
+
+float bf16_round(float v) {
+  uint32_t u; memcpy(&u, &v, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return v;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  u &= 0xffff0000u;
+  float r; memcpy(&r, &u, 4);
+  return r;
+}
+
+float fp8_column_scale(float maxabs) {
+  if (!(maxabs > 0.0f)) return 1.0f;
+  int e; const float f = frexpf(maxabs / 448.0f, &e);        // maxabs/448 = f * 2^e, f in [0.5, 1)
+  if (f == 0.5f) e -= 1;
+  return ldexpf(1.0f, std::max(-100, std::min(100, e)));
+}
+
+void quantize_matrix(float* w, int K, int N, bool kn, int fmt) {
+  if (fmt == WFMT_F32) return;
+  auto at = [&](int k, int n) -> float& { return kn ? w[(size_t)k * N + n] : w[(size_t)n * K + k]; };
+  if (fmt == WFMT_BF16) {
+    for (size_t i = 0; i < (size_t)K * N; ++i) w[i] = bf16_round(w[i]);
+    return;
+  }
+  std::vector<float> mx(N, 0.0f);
+  for (int k = 0; k < K; ++k)
+    for (int n = 0; n < N; ++n) mx[n] = std::max(mx[n], std::fabs(at(k, n)));
+  for (int n = 0; n < N; ++n) mx[n] = fp8_column_scale(mx[n]);
+  for (int k = 0; k < K; ++k)
+    for (int n = 0; n < N; ++n) { float& v = at(k, n); v = mx[n] * fp8_e4m3_decode(fp8_e4m3_encode(v / mx[n])); }
+}
+
+int compact_gemv16(void* dst, const float* pk, int N, int K, int fmt, float* scale_out) {
+  const int NT = cdiv(N, 16), KC = cdiv(K, 16);
+  const size_t total = (size_t)NT * KC * 256;
+  if (fmt == WFMT_BF16) {
+    uint16_t* o = static_cast<uint16_t*>(dst);
+    for (size_t i = 0; i < total; ++i) {
+      uint32_t u; memcpy(&u, &pk[i], 4);
+      if (u & 0xffffu) return 1;
+      o[i] = (uint16_t)(u >> 16);
+    }
+    return 0;
+  }
+  if (fmt != WFMT_FP8) return 1;
+  std::vector<float> mx(NT * 16, 0.0f);
+  for (int nt = 0; nt < NT; ++nt)
+    for (int c = 0; c < KC; ++c) {
+      const float* sub = pk + ((size_t)nt * KC + c) * 256;
+      for (int i = 0; i < 256; ++i) { float& m = mx[nt * 16 + ((i >> 2) & 15)]; m = std::max(m, std::fabs(sub[i])); }
+    }
+  for (int n = 0; n < NT * 16; ++n) { mx[n] = fp8_column_scale(mx[n]); if (n < N) scale_out[n] = mx[n]; }
+  unsigned char* o = static_cast<unsigned char*>(dst);
+  for (int nt = 0; nt < NT; ++nt)
+    for (int c = 0; c < KC; ++c) {
+      const size_t base = ((size_t)nt * KC + c) * 256;
+      for (int i = 0; i < 256; ++i) {
+        const float s = mx[nt * 16 + ((i >> 2) & 15)], v = pk[base + i];
+        const unsigned char q = fp8_e4m3_encode(v / s);
+        if (s * fp8_e4m3_decode(q) != v) return 1;
+        o[base + i] = q;
+      }
+    }
+  return 0;
+}
+
+__global__ void fp8_decode_table_kernel(float* out) {
+  const int c = threadIdx.x;      // 256 codes
+  const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8(c, false);
+  out[c] = lo[0];
+}
+
+int fp8_check_device_decode(hipStream_t stream) {
+  static bool ok = false;
+  if (ok) return 0;
+  float* d = nullptr;
+  IDX_HIP(hipMalloc(&d, 256 * sizeof(float)));
+  hipLaunchKernelGGL(fp8_decode_table_kernel, dim3(1), dim3(256), 0, stream, d);
+  float h[256];
+  hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(d);
+  IDX_HIP(e);
+  for (int c = 0; c < 256; ++c) {
+    const float want = fp8_e4m3_decode((unsigned char)c);
+    if (std::isnan(want)) continue;
+    if (!(h[c] == want)) IDX_FAIL("this device's fp8 conversion is not OCP e4m3fn (code " + std::to_string(c) + ")");
+  }
+  ok = true;
+  return 0;
+}
+
 struct GemvFXP {
   const float* xf;          // A-fragment images [MT][kc16][64][4]
-  const float* wp;          // packed weights [ntiles][kc16][64][4]
+  const void* wp;           // packed weights [ntiles][kc16][64][4] elements of the WT format
+  const float* wscale;      // fp8: [N] power-of-two column scales (null otherwise)
   const float* bias;        // [N] or null (LN-folded layers: c = b.W + bias)
   const float* colsum;      // [N] LN-folded layers: u = colsum(diag(g) W); null = plain GEMV
   float ln_eps;
@@ -78,8 +195,33 @@ __device__ __forceinline__ float gelu_new_fx(float v) {
 template <int MT, int NTW, bool SINGLE>
 struct FXCfg { static constexpr int UN = SINGLE ? 5 : ((MT + NTW == 2) ? 5 : (NTW == 2 ? 3 : (MT == 2 ? 2 : 1))); };
 
-template <int MT, int NTW, bool SINGLE>
+// What one lane reads of a 16-k weight chunk (4 weights) in each storage format, and how it widens to fp32 (exact)
+template <int WT> struct WRaw;
+template <> struct WRaw<WFMT_F32> {
+  typedef f32x4 raw;
+  static __device__ __forceinline__ raw zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ f32x4 widen(raw r) { return r; }
+};
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+template <> struct WRaw<WFMT_BF16> {
+  typedef u32x2_t raw;
+  static __device__ __forceinline__ raw zero() { return raw{0u, 0u}; }
+  static __device__ __forceinline__ f32x4 widen(raw r) {
+    return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
+  }
+};
+template <> struct WRaw<WFMT_FP8> {
+  typedef uint32_t raw;
+  static __device__ __forceinline__ raw zero() { return 0u; }
+  static __device__ __forceinline__ f32x4 widen(raw r) {
+    const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)r, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)r, true);
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+  }
+};
+
+template <int MT, int NTW, bool SINGLE, int WT>
 __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
+  typedef typename WRaw<WT>::raw wraw_t;
   constexpr int UN = FXCfg<MT, NTW, SINGLE>::UN;
   constexpr int NB = SINGLE ? 1 : 2;
   constexpr int NACC = MT * NTW;
@@ -101,8 +243,9 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
   const int e_row = e_mt * 16 + (e_ln >> 4) * 4 + e_r, e_col = (nt0 + e_ntw) * 16 + (e_ln & 15);
   const bool e_ok = e_t < NACC && e_row < p.rows && e_col < p.N;
   size_t e_addr = 0;
-  float e_bias = 0.f, e_u = 0.f, e_res = 0.f;
+  float e_bias = 0.f, e_u = 0.f, e_res = 0.f, e_s = 1.f;
   if (e_ok) {
+    if (WT == WFMT_FP8) e_s = p.wscale[e_col];
     e_addr = p.y_frag ? frag_index(e_row, e_col, p.N >> 4) : (size_t)e_row * p.ldy + e_col;
     if (p.ksb > 1) e_addr = ((size_t)blockIdx.y * p.rows + e_row) * p.N + e_col;
     if (p.bias) e_bias = p.bias[e_col];
@@ -116,20 +259,21 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int j = 0; j < NTW; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* wbase[NTW];
+  const wraw_t* wbase[NTW];      // one raw element = this lane's 4 weights of a chunk; 64 per chunk
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) wbase[j] = p.wp + ((size_t)min(nt0 + j, p.ntiles - 1) * p.kc16 + c0) * 256 + lane * 4;
+  for (int j = 0; j < NTW; ++j) wbase[j] = static_cast<const wraw_t*>(p.wp) + ((size_t)min(nt0 + j, p.ntiles - 1) * p.kc16 + c0) * 64 + lane;
   const float* xbase = p.xf + (size_t)c0 * 256 + lane * 4;
   const size_t ximg = (size_t)p.kc16 * 256;
 
-  f32x4 wq[NB][UN][NTW], xq[NB][UN][MT];
+  wraw_t wq[NB][UN][NTW];
+  f32x4 xq[NB][UN][MT];
   auto load_batch = [&](int buf, int cb) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const bool ok = cb + u < nch;
 #pragma unroll
       for (int j = 0; j < NTW; ++j)
-        wq[buf][u][j] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wbase[j] + (size_t)(cb + u) * 256)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        wq[buf][u][j] = ok ? __builtin_nontemporal_load(wbase[j] + (size_t)(cb + u) * 64) : WRaw<WT>::zero();
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
         xq[buf][u][mt] = (ok && !(p.dbg & 1)) ? *reinterpret_cast<const f32x4*>(xbase + mt * ximg + (size_t)(cb + u) * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -158,11 +302,14 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
             s2[mt] += dlt * dlt;
           }
       }
+      f32x4 wf[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) wf[j] = WRaw<WT>::widen(wq[buf][u][j]);
       if (p.dbg & 2) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) acc[mt][j] += xq[buf][u][mt] * wq[buf][u][j];
+          for (int j = 0; j < NTW; ++j) acc[mt][j] += xq[buf][u][mt] * wf[j];
       } else {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -170,7 +317,7 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int j = 0; j < NTW; ++j)
-              acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[buf][u][mt][s], wq[buf][u][j][s], acc[mt][j], 0, 0, 0);
+              acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[buf][u][mt][s], wf[j][s], acc[mt][j], 0, 0, 0);
       }
     }
   };
@@ -239,6 +386,7 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
     float v = 0.f;
     for (int w = 0; w < p.kw; ++w) v += redbuf[(w * NACC + e_t) * 256 + (tid & 255)];
     if (e_ok) {
+      if (WT == WFMT_FP8) v *= e_s;        // power-of-two column scale: exact
       if (ln) v = rstat[e_row * 2 + 1] * (v - rstat[e_row * 2] * e_u);
       v += e_bias;
       if (p.act == 1) v = gelu_new_fx(v);
@@ -304,7 +452,8 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
   if (a.colsum) IDX_CHECK(w.K % 16 == 0, "folded LayerNorm needs K % 16 == 0");
   if (a.y_frag) IDX_CHECK(w.N % 16 == 0, "fragment-image output needs N % 16 == 0");
   GemvFXP p;
-  p.xf = a.xf; p.wp = w.wp; p.bias = a.bias; p.colsum = a.colsum; p.ln_eps = a.ln_eps;
+  IDX_CHECK(w.fmt == WFMT_F32 || w.fmt == WFMT_BF16 || (w.fmt == WFMT_FP8 && w.wscale), "weight format");
+  p.xf = a.xf; p.wp = w.wp; p.wscale = w.wscale; p.bias = a.bias; p.colsum = a.colsum; p.ln_eps = a.ln_eps;
   p.res = a.res; p.y = a.y; p.y_frag = a.y_frag; p.ldy = a.ldy;
   p.rows = a.rows; p.N = w.N; p.K = w.K; p.kc16 = cdiv(w.K, 16); p.ntiles = cdiv(w.N, 16);
   int ntw = 1;
@@ -320,17 +469,23 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
   const size_t lds = (size_t)(p.kw * nacc * 256 + p.kw * MT * 32 + MT * 32) * sizeof(float);
   dim3 grid(cdiv(p.ntiles, ntw), p.ksb);
   const double flops = 2.0 * a.rows * (double)w.N * w.K;
-  const double bytes = 4.0 * ((double)w.N * w.K + (double)a.rows * w.N * (a.res ? 2.0 : 1.0) + (double)a.rows * w.K);
+  const double bytes = (double)wfmt_bytes(w.fmt) * w.N * w.K + 4.0 * ((double)a.rows * w.N * (a.res ? 2.0 : 1.0) + (double)a.rows * w.K);
   ProfScope prof(PROF_GEMV16, stream, flops, bytes);
-#define LAUNCH(MTV, NTWV, SG)                                                                                             \
+#define LAUNCH_W(MTV, NTWV, SG, WTV)                                                                                      \
   {                                                                                                                       \
     static bool attr_set = false;                                                                                         \
     if (!attr_set) {                                                                                                      \
-      IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_fx_kernel<MTV, NTWV, SG>),                           \
+      IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_fx_kernel<MTV, NTWV, SG, WTV>),                      \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                               \
       attr_set = true;                                                                                                    \
     }                                                                                                                     \
-    hipLaunchKernelGGL((gemv_fx_kernel<MTV, NTWV, SG>), grid, dim3(threads), lds, stream, p);                             \
+    hipLaunchKernelGGL((gemv_fx_kernel<MTV, NTWV, SG, WTV>), grid, dim3(threads), lds, stream, p);                        \
+  }
+#define LAUNCH(MTV, NTWV, SG)                                                                                             \
+  {                                                                                                                       \
+    if (w.fmt == WFMT_FP8) LAUNCH_W(MTV, NTWV, SG, WFMT_FP8)                                                              \
+    else if (w.fmt == WFMT_BF16) LAUNCH_W(MTV, NTWV, SG, WFMT_BF16)                                                       \
+    else LAUNCH_W(MTV, NTWV, SG, WFMT_F32)                                                                                \
   }
   const bool single = p.cps <= 5;
   if (MT == 1 && ntw == 2 && single) LAUNCH(1, 2, true)
@@ -338,6 +493,7 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
   else if (MT == 1 && single) LAUNCH(1, 1, true)
   else if (MT == 1) LAUNCH(1, 1, false)
   else if (MT == 2) LAUNCH(2, 1, false) else if (MT == 3) LAUNCH(3, 1, false) else LAUNCH(4, 1, false)
+#undef LAUNCH_W
 #undef LAUNCH
   IDX_LAUNCH_CHECK();
   return 0;

@@ -25,6 +25,7 @@ struct GPTModel : ModelBase {
   Gemv16Weights head_g;
   const float* head_b = nullptr;
   const float *mel_emb = nullptr, *text_emb = nullptr, *mel_pos = nullptr, *text_pos = nullptr;
+  int weight_fmt = WFMT_F32;      // storage format of the decode weight streams (quantize_weights)
   hipStream_t own_stream = nullptr;
   ~GPTModel() override { if (own_stream) (void)hipStreamDestroy(own_stream); }
 
@@ -42,6 +43,10 @@ struct GPTModel : ModelBase {
   explicit GPTModel(const idxtts_gpt_config& c);
   bool accepts(const std::string& name) const override;
   int finalize(std::map<std::string, HostTensor>& t, DeviceArena& arena) override;
+  // Host transform of the staged tensors (before finalize) into the model a compact decode format can hold exactly:
+  //   (ln_g, ln_b, W, b) of c_attn / c_fc -> (1, 0, Q(diag(ln_g) W), ln_b . W + b);  c_proj, mlp.c_proj, mel_head -> Q(W).
+  // Every consumer (prefill, latent pass, decode) is then packed from these tensors, so they all run the SAME model.
+  int quantize_weights(std::map<std::string, HostTensor>& t, int fmt);
   Buffers carve(void* ws, int B, int S, int max_new) const;
   size_t workspace_bytes(int B, int S, int max_new) const;
   int layer_full(int li, const Buffers& w, int B, int S, const int* kstart, bool store_kv, hipStream_t st);

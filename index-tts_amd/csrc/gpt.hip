@@ -49,7 +49,30 @@ static int upload(std::map<std::string, HostTensor>& t, DeviceArena& arena, cons
 // HF Conv1D weight [K][N] -> both packed forms
 // ln_g / ln_b (host, [K]) non-null: the decode copy gets the LayerNorm in front of it folded in (gemv_fx.hip):
 //   W' = diag(g) W (packed), u = colsum(W'), c = b . W + bias
-static int make_proj(std::map<std::string, HostTensor>& t, DeviceArena& arena, const std::string& prefix, int K, int N,
+// decode stream in the model's storage format (the fp32 pack `buf` holds values the format represents exactly)
+static int upload_stream(DeviceArena& arena, const std::vector<float>& buf, int N, int K, int fmt, Gemv16Weights* gw) {
+  gw->N = N; gw->K = K; gw->fmt = fmt;
+  if (fmt == WFMT_F32) {
+    float* d = nullptr;
+    if (arena.upload(buf.data(), buf.size(), &d)) return 1;
+    gw->wp = d;
+    return 0;
+  }
+  std::vector<unsigned char> cbuf(buf.size() * wfmt_bytes(fmt));
+  std::vector<float> scale(N, 1.0f);
+  if (compact_gemv16(cbuf.data(), buf.data(), N, K, fmt, scale.data())) IDX_FAIL("decode weights are not representable in the compact format (quantize_weights not applied?)");
+  void* d = nullptr;
+  if (arena.upload_bytes(cbuf.data(), cbuf.size(), &d)) return 1;
+  gw->wp = d;
+  if (fmt == WFMT_FP8) {
+    float* ds = nullptr;
+    if (arena.upload(scale.data(), scale.size(), &ds)) return 1;
+    gw->wscale = ds;
+  }
+  return 0;
+}
+
+static int make_proj(std::map<std::string, HostTensor>& t, DeviceArena& arena, const std::string& prefix, int K, int N, int fmt,
                      LinearWeights* lw, Gemv16Weights* gw, const HostTensor* ln_g = nullptr, const HostTensor* ln_b = nullptr,
                      const float** u_out = nullptr, const float** c_out = nullptr) {
   HostTensor* w = nullptr;
@@ -95,8 +118,47 @@ static int make_proj(std::map<std::string, HostTensor>& t, DeviceArena& arena, c
   } else {
     pack_gemv16_kn(buf.data(), w->data.data(), K, N);
   }
-  if (arena.upload(buf.data(), buf.size(), &d)) return 1;
-  gw->wp = d; gw->N = N; gw->K = K;
+  return upload_stream(arena, buf, N, K, fmt, gw);
+}
+
+int GPTModel::quantize_weights(std::map<std::string, HostTensor>& t, int fmt) {
+  IDX_CHECK(fmt == WFMT_F32 || fmt == WFMT_BF16 || fmt == WFMT_FP8, "weight format: 0 fp32, 1 bf16, 2 fp8-e4m3 + power-of-two column scale");
+  IDX_CHECK(weight_fmt == WFMT_F32, "weights already quantised");
+  if (fmt == WFMT_F32) return 0;
+  if (fmt == WFMT_FP8 && fp8_check_device_decode(nullptr)) return 1;
+  const int d = cfg.model_dim, f = 4 * d;
+  auto fold = [&](const std::string& ln, const std::string& proj, int K, int N) -> int {
+    HostTensor *g = nullptr, *b = nullptr, *w = nullptr, *bias = nullptr;
+    if (need(t, ln + ".weight", {K}, &g) || need(t, ln + ".bias", {K}, &b) || need(t, proj + ".weight", {K, N}, &w) ||
+        need(t, proj + ".bias", {N}, &bias)) return 1;
+    std::vector<double> cd(N, 0.0);
+    for (int k = 0; k < K; ++k) {
+      const float gk = g->data[k];
+      const double bk = b->data[k];
+      float* row = &w->data[(size_t)k * N];
+      for (int n = 0; n < N; ++n) { cd[n] += bk * (double)row[n]; row[n] = gk * row[n]; }
+    }
+    for (int n = 0; n < N; ++n) bias->data[n] = (float)(cd[n] + (double)bias->data[n]);
+    quantize_matrix(w->data.data(), K, N, true, fmt);
+    std::fill(g->data.begin(), g->data.end(), 1.0f);
+    std::fill(b->data.begin(), b->data.end(), 0.0f);
+    return 0;
+  };
+  auto plain = [&](const std::string& proj, int K, int N) -> int {
+    HostTensor* w = nullptr;
+    if (need(t, proj + ".weight", {K, N}, &w)) return 1;
+    quantize_matrix(w->data.data(), K, N, true, fmt);
+    return 0;
+  };
+  for (int i = 0; i < cfg.layers; ++i) {
+    const std::string p = "gpt.h." + std::to_string(i);
+    if (fold(p + ".ln_1", p + ".attn.c_attn", d, 3 * d) || plain(p + ".attn.c_proj", d, d)) return 1;
+    if (fold(p + ".ln_2", p + ".mlp.c_fc", d, f) || plain(p + ".mlp.c_proj", f, d)) return 1;
+  }
+  HostTensor* hw = nullptr;
+  if (need(t, "mel_head.weight", {cfg.number_mel_codes, d}, &hw)) return 1;
+  quantize_matrix(hw->data.data(), d, cfg.number_mel_codes, false, fmt);
+  weight_fmt = fmt;
   return 0;
 }
 
@@ -113,10 +175,10 @@ int GPTModel::finalize(std::map<std::string, HostTensor>& t, DeviceArena& arena)
     HostTensor *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
     if (need(t, p + ".ln_1.weight", {d}, &g1) || need(t, p + ".ln_1.bias", {d}, &b1)) return 1;
     if (need(t, p + ".ln_2.weight", {d}, &g2) || need(t, p + ".ln_2.bias", {d}, &b2)) return 1;
-    if (make_proj(t, arena, p + ".attn.c_attn", d, 3 * d, &L.attn_l, &L.attn_g, g1, b1, &L.attn_u, &L.attn_c)) return 1;
-    if (make_proj(t, arena, p + ".attn.c_proj", d, d, &L.proj_l, &L.proj_g)) return 1;
-    if (make_proj(t, arena, p + ".mlp.c_fc", d, f, &L.fc_l, &L.fc_g, g2, b2, &L.fc_u, &L.fc_c)) return 1;
-    if (make_proj(t, arena, p + ".mlp.c_proj", f, d, &L.fc2_l, &L.fc2_g)) return 1;
+    if (make_proj(t, arena, p + ".attn.c_attn", d, 3 * d, weight_fmt, &L.attn_l, &L.attn_g, g1, b1, &L.attn_u, &L.attn_c)) return 1;
+    if (make_proj(t, arena, p + ".attn.c_proj", d, d, weight_fmt, &L.proj_l, &L.proj_g)) return 1;
+    if (make_proj(t, arena, p + ".mlp.c_fc", d, f, weight_fmt, &L.fc_l, &L.fc_g, g2, b2, &L.fc_u, &L.fc_c)) return 1;
+    if (make_proj(t, arena, p + ".mlp.c_proj", f, d, weight_fmt, &L.fc2_l, &L.fc2_g)) return 1;
   }
   if (upload(t, arena, "gpt.ln_f.weight", {d}, &lnf_g) || upload(t, arena, "gpt.ln_f.bias", {d}, &lnf_b)) return 1;
   if (upload(t, arena, "final_norm.weight", {d}, &fn_g) || upload(t, arena, "final_norm.bias", {d}, &fn_b)) return 1;
@@ -125,9 +187,7 @@ int GPTModel::finalize(std::map<std::string, HostTensor>& t, DeviceArena& arena)
   if (need(t, "mel_head.weight", {V, d}, &hw)) return 1;
   std::vector<float> buf(gemv16_packed_floats(V, d));
   pack_gemv16_nk(buf.data(), hw->data.data(), V, d);
-  float* dp = nullptr;
-  if (arena.upload(buf.data(), buf.size(), &dp)) return 1;
-  head_g.wp = dp; head_g.N = V; head_g.K = d;
+  if (upload_stream(arena, buf, V, d, weight_fmt, &head_g)) return 1;
   if (upload(t, arena, "mel_head.bias", {V}, &head_b)) return 1;
   if (upload(t, arena, "mel_embedding.weight", {V, d}, &mel_emb)) return 1;
   if (upload(t, arena, "text_embedding.weight", {cfg.number_text_tokens + 1, d}, &text_emb)) return 1;

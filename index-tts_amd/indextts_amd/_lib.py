@@ -16,11 +16,12 @@ LIB_PATH = os.path.join(_HERE, "libidxtts_hip.so")
 SYMBOLS = [
     "idxtts_version", "idxtts_last_error", "idxtts_aa_act_fwd",
     "idxtts_conv1d_create", "idxtts_conv1d_fwd", "idxtts_conv1d_destroy",
-    "idxtts_ctx_load_tensor", "idxtts_ctx_finalize", "idxtts_ctx_destroy",
+    "idxtts_ctx_load_tensor", "idxtts_ctx_finalize", "idxtts_ctx_get_tensor", "idxtts_ctx_destroy",
+    "idxtts_fp8_e4m3_decode", "idxtts_fp8_e4m3_encode",
     "idxtts_bigvgan_create", "idxtts_bigvgan_workspace_bytes", "idxtts_bigvgan_fwd", "idxtts_bigvgan_fwd_ragged",
     "idxtts_profile_enable", "idxtts_profile_num_kernels", "idxtts_profile_kernel_name", "idxtts_profile_read",
     "idxtts_linear_create", "idxtts_linear_fwd", "idxtts_linear_destroy", "idxtts_attention_fwd", "idxtts_attention_bf16x3_fwd", "idxtts_layernorm_fwd",
-    "idxtts_gpt_create", "idxtts_gpt_workspace_bytes", "idxtts_gpt_embed", "idxtts_gpt_generate", "idxtts_gpt_generate_sampled", "idxtts_gpt_latent",
+    "idxtts_gpt_create", "idxtts_gpt_quantize_weights", "idxtts_gpt_workspace_bytes", "idxtts_gpt_embed", "idxtts_gpt_generate", "idxtts_gpt_generate_sampled", "idxtts_gpt_latent",
     "idxtts_s2mel_create", "idxtts_s2mel_cond_workspace_bytes", "idxtts_s2mel_prepare_cond",
     "idxtts_s2mel_cfm_workspace_bytes", "idxtts_s2mel_cfm", "idxtts_set_gemm_mode", "idxtts_get_gemm_mode",
 ]
@@ -75,6 +76,12 @@ def load() -> ctypes.CDLL:
     lib.idxtts_conv1d_destroy.argtypes = [c_void_p]
     lib.idxtts_ctx_load_tensor.argtypes = [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]
     lib.idxtts_ctx_finalize.argtypes = [c_void_p]
+    lib.idxtts_ctx_get_tensor.argtypes = [c_void_p, c_char_p, c_void_p, c_size_t]
+    lib.idxtts_fp8_e4m3_decode.argtypes = [ctypes.c_ubyte]
+    lib.idxtts_fp8_e4m3_decode.restype = ctypes.c_float
+    lib.idxtts_fp8_e4m3_encode.argtypes = [ctypes.c_float]
+    lib.idxtts_fp8_e4m3_encode.restype = ctypes.c_ubyte
+    lib.idxtts_gpt_quantize_weights.argtypes = [c_void_p, c_int]
     lib.idxtts_ctx_destroy.argtypes = [c_void_p]
     lib.idxtts_bigvgan_create.argtypes = [POINTER(BigVGANConfigC), POINTER(c_void_p)]
     lib.idxtts_bigvgan_workspace_bytes.argtypes = [c_void_p, c_int, c_int]
@@ -138,8 +145,9 @@ def current_stream() -> c_void_p:
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def load_state_dict(ctx: c_void_p, state_dict) -> None:
-    """Hand every tensor of a (reference-layout) state dict to the context, then finalize it."""
+def load_state_dict(ctx: c_void_p, state_dict, before_finalize=None) -> None:
+    """Hand every tensor of a (reference-layout) state dict to the context, then finalize it.
+    before_finalize(ctx): optional hook between the last tensor and finalize (weight quantisation, read-back)."""
     import numpy as np
     import torch
     lib = load()
@@ -154,7 +162,17 @@ def load_state_dict(ctx: c_void_p, state_dict) -> None:
             dptr = c_void_p(arr.ctypes.data)
         cshape = (c_int64 * max(1, len(shape)))(*shape)
         check(lib.idxtts_ctx_load_tensor(ctx, name.encode(), dptr, cshape, len(shape)))
+    if before_finalize is not None:
+        before_finalize(ctx)
     check(lib.idxtts_ctx_finalize(ctx))
+
+
+def get_tensor(ctx: c_void_p, name: str, shape):
+    """Staged (not yet finalized) tensor `name` as a numpy fp32 array of `shape`."""
+    import numpy as np
+    out = np.empty(shape, dtype=np.float32)
+    check(load().idxtts_ctx_get_tensor(ctx, name.encode(), c_void_p(out.ctypes.data), out.size))
+    return out
 
 
 def profile_enable(on: bool) -> None:

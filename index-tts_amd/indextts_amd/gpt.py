@@ -29,9 +29,20 @@ def _i32(dev, arr) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)).to(dev)
 
 
+WEIGHT_FORMATS = {"f32": 0, "bf16": 1, "fp8": 2}
+
+
 class UnifiedVoice:
-    def __init__(self, state_dict, cfg: GPTConfig = GPTConfig(), device="cuda:0"):
+    def __init__(self, state_dict, cfg: GPTConfig = GPTConfig(), device="cuda:0", weight_format: str = "f32", keep_effective: bool = False):
+        """weight_format: storage of the GPT's linear weights -- "f32" (default), "bf16", or "fp8" (e4m3 + power-of-two scale
+        per output channel): the reference's `use_fp16` switch (infer_v2.py:145-146) / BASELINE configs[4].  The weights are
+        rounded ONCE at load (`idxtts_gpt_quantize_weights`); the arithmetic stays fp32, and every pass runs that one rounded
+        model.  keep_effective: keep `self.effective_state_dict` (numpy, reference keys) = exactly that model, for parity checks."""
         lib = _lib.load()
+        if weight_format not in WEIGHT_FORMATS:
+            raise ValueError(f"weight_format must be one of {sorted(WEIGHT_FORMATS)}")
+        self.weight_format = weight_format
+        self.effective_state_dict = None
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -43,7 +54,13 @@ class UnifiedVoice:
             _lib.check(lib.idxtts_gpt_create(ctypes.byref(c), ctypes.byref(h)))
             self._h = h
             sd = {k: v for k, v in state_dict.items() if self._on_path(k)}
-            _lib.load_state_dict(h, sd)
+
+            def hook(ctx):
+                if WEIGHT_FORMATS[weight_format]:
+                    _lib.check(lib.idxtts_gpt_quantize_weights(ctx, WEIGHT_FORMATS[weight_format]))
+                if keep_effective:
+                    self.effective_state_dict = {k: _lib.get_tensor(ctx, k, tuple(v.shape)) for k, v in sd.items()}
+            _lib.load_state_dict(h, sd, before_finalize=hook)
         se = state_dict["speed_emb.weight"]
         self.speed_emb = (se if isinstance(se, torch.Tensor) else torch.from_numpy(np.asarray(se))).float().to(self.device)
         self._ws = None

@@ -354,3 +354,87 @@ def test_full_size_greedy_and_latent_vs_oracle(device):
         with torch.no_grad():
             want = og.latent_forward(tw, cfg, lat[b:b + 1], text[b:b + 1, :tl], ref[b:b + 1], emo[b:b + 1])
         assert (got[b:b + 1] - want).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item()), b
+
+
+# ---- compact weight storage (BASELINE configs[4]: fp8 GPT weights; `use_fp16`-like bf16) ------------------------------------
+def _fp8_grid():
+    """Every finite OCP e4m3fn value, restated independently of the library (bias 7, 3 mantissa bits, max 448)."""
+    vals = []
+    for c in range(127):
+        e, m = (c >> 3) & 15, c & 7
+        vals.append(m / 8 * 2.0 ** -6 if e == 0 else (1 + m / 8) * 2.0 ** (e - 7))
+    return np.array(vals, dtype=np.float64)
+
+
+def _check_effective(orig, eff, cfg, fmt):
+    """The read-back model is (ln = identity affine, Q(diag(g) W), b_ln . W + b) with Q = the format's rounding."""
+    grid = _fp8_grid()
+    for i in range(cfg.layers):
+        p = f"gpt.h.{i}"
+        for ln, proj in ((".ln_1", ".attn.c_attn"), (".ln_2", ".mlp.c_fc"), (None, ".attn.c_proj"), (None, ".mlp.c_proj")):
+            W = orig[p + proj + ".weight"].astype(np.float64)
+            if ln:
+                g, b = orig[p + ln + ".weight"], orig[p + ln + ".bias"].astype(np.float64)
+                assert np.all(eff[p + ln + ".weight"] == 1.0) and np.all(eff[p + ln + ".bias"] == 0.0)
+                c = b @ W + orig[p + proj + ".bias"]
+                assert np.abs(eff[p + proj + ".bias"] - c).max() <= 1e-6 * max(1.0, np.abs(c).max())
+                W = (g[:, None] * orig[p + proj + ".weight"]).astype(np.float64)     # the fold is an fp32 product
+            Q = eff[p + proj + ".weight"].astype(np.float64)
+            if fmt == "bf16":
+                assert np.all((eff[p + proj + ".weight"].view(np.uint32) & 0xffff) == 0)
+                assert np.all(np.abs(Q - W) <= 2.0 ** -8 * np.abs(W))       # half an ulp of 8 significant bits
+            else:
+                mx = np.abs(W).max(axis=0)
+                s = 2.0 ** np.ceil(np.log2(np.maximum(mx, 1e-30) / 448.0))
+                q = np.abs(Q) / s
+                assert np.all(np.isin(q, grid)), "not an e4m3 value x power-of-two column scale"
+                # nearest grid point (ties may go either way here; the library rounds them to the even code)
+                assert np.all(np.abs(q - np.abs(W) / s) <= np.abs(grid[None, None, :] - (np.abs(W) / s)[..., None]).min(axis=-1) + 1e-12)
+
+
+@pytest.mark.parametrize("fmt", ["bf16", "fp8"])
+def test_compact_weights_generate_and_latent_vs_oracle_on_the_same_model(device, fmt):
+    """Weights stored as bf16 / fp8-e4m3 (+ power-of-two column scale): the rounded model is read back through the C ABI and
+    handed to the fp32 CPU oracle -- greedy codes bit-exact, latent within the fp32 tolerance; and the read-back model is
+    checked to be exactly the documented rounding of the original one."""
+    from indextts_amd.gpt import UnifiedVoice
+    from oracle import gpt as og
+    cfg = GPTConfig(model_dim=128, heads=2, layers=3, number_mel_codes=210, number_text_tokens=60, start_mel_token=208, stop_mel_token=209,
+                    max_mel_tokens=60, max_text_tokens=30)
+    w = weights.synth_gpt_weights(cfg, tag=f"t/gpt/q/{fmt}")
+    uv = UnifiedVoice(w, cfg, device=device, weight_format=fmt, keep_effective=True)
+    eff = uv.effective_state_dict
+    _check_effective(w, eff, cfg, fmt)
+    tw = {k: torch.from_numpy(v) for k, v in eff.items()}
+    B, L, NEW = 3, 9, 40
+    lat = torch.from_numpy(synth.uniform("t/gpt/q/lat", (B, cfg.cond_latents, cfg.model_dim), 0.5))
+    emo = torch.from_numpy(synth.uniform("t/gpt/q/emo", (B, cfg.model_dim), 0.3))
+    text = torch.from_numpy(synth.integers("t/gpt/q/text", (B, L), 2, cfg.number_text_tokens))
+    codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, repetition_penalty=10.0)
+    with torch.no_grad():
+        ref = og.generate_greedy(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, NEW, 10.0)
+    assert np.array_equal(codes.cpu().numpy(), ref.numpy())
+    n = ref.shape[1]
+    got = uv.forward(lat, text, torch.full((B,), L), codes.cpu(), torch.full((B,), n), emo_vec=emo).cpu()
+    with torch.no_grad():
+        want = og.latent_forward(tw, cfg, lat, text, ref, emo)
+    assert (got - want).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())
+
+
+def test_fp8_full_size_single_utterance_vs_oracle(device):
+    """configs[4] shape: the real GPT, ONE utterance, emotion vector mixed in, fp8 weight streams, graph-replayed decode --
+    codes bit-exact against the oracle run on the read-back fp8 model."""
+    from indextts_amd.gpt import UnifiedVoice
+    from oracle import gpt as og
+    cfg = GPTConfig()
+    w = weights.synth_gpt_weights(cfg, tag="bench/gpt")
+    uv = UnifiedVoice(w, cfg, device=device, weight_format="fp8", keep_effective=True)
+    tw = {k: torch.from_numpy(v) for k, v in uv.effective_state_dict.items()}
+    L, NEW = 12, 10
+    lat = torch.from_numpy(synth.uniform("t/gpt/q8/lat", (1, cfg.cond_latents, cfg.model_dim), 0.5))
+    emo = torch.from_numpy(synth.uniform("t/gpt/q8/emo", (1, cfg.model_dim), 0.3))
+    text = torch.from_numpy(synth.integers("t/gpt/q8/text", (1, L), 2, cfg.number_text_tokens))
+    codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, repetition_penalty=10.0)
+    with torch.no_grad():
+        ref = og.generate_greedy(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, NEW, 10.0)
+    assert np.array_equal(codes.cpu().numpy(), ref.numpy())
