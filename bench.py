@@ -146,7 +146,11 @@ def build_pipeline(args, world, rank, dev):
     ws = weights.synth_s2mel_weights(cfg.s2mel, tag="bench/s2mel")
     wv = weights.synth_bigvgan_weights(cfg.bigvgan, tag="bench/bigvgan")
     log(f"[bench] rank {rank}: synthetic weights in {time.time() - t0:.1f}s")
-    tts = IndexTTS2.from_state_dicts(cfg, wg, ws, wv, device=dev)
+    compact = args.gpt_weights != "f32"
+    tts = IndexTTS2.from_state_dicts(cfg, wg, ws, wv, device=dev, gpt_weight_format=args.gpt_weights,
+                                     keep_effective_gpt=compact and rank == 0 and not args.no_cpu_baseline)
+    if tts.gpt.effective_state_dict is not None:      # the CPU leg runs the SAME (rounded) model the kernels run
+        wg = tts.gpt.effective_state_dict
     cond0 = PromptConditioning.synthetic(cfg, prompt_frames=Tp, tag="bench/prompt")
     shapes = cond0.shapes()
     text = torch.from_numpy(synth.integers(f"bench/text/rank{rank}", (B, L), 2, cfg.gpt.number_text_tokens))
@@ -198,9 +202,11 @@ def build_pipeline(args, world, rank, dev):
                           f"Tp={Tp}, {cfg.diffusion_steps} CFM steps, full-size weights",
                 "greedy_codes_equal_vs_gpu": codes_equal, "mel_l1_vs_gpu": mel_l1, "wav_max_abs_diff_vs_gpu_fullscale": wav_err}
 
-    desc = {"workload": f"configs[2]: IndexTTS-2 full pipeline (gpt 472M + s2mel 98M + BigVGAN 112M params), batch {B} utterances per "
+    desc = {"workload": f"{'configs[4] (long-form, emotion vector, fp8 GPT weights, graph-replayed decode)' if args.longform else 'configs[2]'}: IndexTTS-2 full pipeline (gpt 472M + s2mel 98M + BigVGAN 112M params), batch {B} utterances per "
                         f"GPU, {L} text tokens, {M} codes ({Tg} mel frames, {audio_s / B:.2f} s) each, prompt {Tp} frames, "
-                        f"{cfg.diffusion_steps} CFM steps cfg {cfg.cfg_rate}, greedy decode rep-penalty 10",
+                        f"{cfg.diffusion_steps} CFM steps cfg {cfg.cfg_rate}, greedy decode rep-penalty 10"
+                        + ("" if not compact else f", GPT linear weights stored as {args.gpt_weights} (rounded once at load; fp32 arithmetic)"),
+            "gpt_weights": args.gpt_weights,
             "batch_per_gpu": B, "text_tokens": L, "codes": M, "prompt_frames": Tp, "diffusion_steps": cfg.diffusion_steps}
     return step, profiled, cpu_leg, stage_times, audio_s, desc
 
@@ -210,18 +216,31 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "vocoder"])
+    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "vocoder", "longform"],
+                    help="pipeline = BASELINE configs[2] (the metric's configuration); vocoder = configs[1]; longform = configs[4]: ONE "
+                         "utterance of 1500 codes (30 s), emotion vector mixed in, fp8 GPT weights, graph-replayed decode")
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--frames", type=int, default=800, help="vocoder workload: mel frames")
     ap.add_argument("--text-tokens", type=int, default=128)
-    ap.add_argument("--codes", type=int, default=512)
+    ap.add_argument("--codes", type=int, default=0, help="codes per utterance (default 512; longform 1500)")
     ap.add_argument("--prompt-frames", type=int, default=689)
     ap.add_argument("--cpu-codes", type=int, default=96, help="codes of the bounded CPU-baseline utterance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gpt-weights", default=None, choices=["f32", "bf16", "fp8"],
+                    help="storage of the GPT linear weights (decode is bound by the weight stream): fp32 (default: the reference's "
+                         "own weights, bit for bit), bf16, or fp8-e4m3 with a power-of-two scale per output channel (BASELINE configs[4]); "
+                         "arithmetic stays fp32; the CPU baseline / parity leg runs the same rounded model")
     ap.add_argument("--gemm", default="bf16x3", choices=["bf16x3", "f32"],
                     help="arithmetic of the GEMM-shaped passes (s2mel, latent pass): split-bf16 (default) or exact fp32 MFMA")
     args = ap.parse_args()
+    longform = args.workload == "longform"
+    if longform:
+        args.workload = "pipeline"
+        args.batch = args.batch or 1
+    args.codes = args.codes or (1500 if longform else 512)
+    args.gpt_weights = args.gpt_weights or ("fp8" if longform else "f32")
+    args.longform = longform
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -294,6 +313,8 @@ def main() -> int:
         else:
             dtype = ("f32 (greedy decode + its prefill: exact fp32 MFMA; fp32 accumulate and fp32 activations everywhere) + split-bf16 "
                      "(fp32 operands as hi+lo bf16, 3 bf16 MFMAs per product) GEMMs, DiT attention and convolutions in s2mel, the latent pass and the vocoder")
+        if args.workload == "pipeline" and args.gpt_weights != "f32":
+            dtype += f"; GPT linear weights STORED as {args.gpt_weights} (rounded once at load, widened to fp32 in registers)"
         audio_total = audio_s_per_step_per_gpu * world * args.steps
         value = audio_total / elapsed
         cfgd = dict(desc)
@@ -310,6 +331,9 @@ def main() -> int:
         }
         if stages:
             res["stage_seconds"] = stages
+            ntok = cfgd["batch_per_gpu"] * cfgd["codes"]
+            res["decode"] = {"tokens_per_s": round(ntok / stages["gpt_gen_time"], 1), "ms_per_token_step": round(1000 * stages["gpt_gen_time"] / cfgd["codes"], 4),
+                             "note": "gpt_gen_time includes the prefill; one step = one token for every utterance of the batch"}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -46,7 +46,11 @@ struct GemvFXArgs {
   int act = 0;                                    // 0 none, 1 gelu_new
   const float* res = nullptr;                     // residual in the layout of y (may alias y)
   float* y = nullptr; int y_frag = 0; int ldy = 0;   // y_frag: fragment images over N, else row-major [rows][ldy]
-  int ksb = 1;                                    // > 1 (gemv_fx_ksb): y = raw K-slice partial sums [ksb][rows][N]; no epilogue operands
+  int ksb = 1;                                    // > 1 (gemv_fx_ksb): K also split across workgroups.  Without `ksb_counters`:
+                                                  // y = raw partial sums [ksb][rows][N], no epilogue operands (gemv_fx_combine adds them).
+  float* slab = nullptr;                          // With `ksb_counters` (+ slab [ksb][rows][N]): the LAST workgroup of a column tile to
+  unsigned* ksb_counters = nullptr;               // arrive adds the partial sums in slab order (fixed, whoever is last) and runs the normal
+                                                  // epilogue into y; counters [ceil(N/16)] start at 0 and are left at 0
   int dbg = 0;                                    // ablation mask for tools/gemv_probe.hip only
 };
 int gemv_fx_ksb(int N, int K);

@@ -180,6 +180,8 @@ struct GemvFXP {
   float* y; int y_frag; int ldy;   // y_frag: fragment images with kc16 = N/16 (N % 16 == 0), else row-major [rows][ldy]
   int rows, N, K, kc16, ntiles, kw, cps, act;
   int ksb;                  // > 1: K also split across gridDim.y workgroups; y = raw partial sums [ksb][rows][N] (row-major)
+  float* slab;              // fused K-split: partial sums [ksb][rows][N]; the last workgroup of a column tile finishes the job
+  unsigned* cnt;            // [gridDim.x] arrival counters (0 on entry and on exit); null = unfused
   int dbg;
 };
 
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
   if (e_ok) {
     if (WT == WFMT_FP8) e_s = p.wscale[e_col];
     e_addr = p.y_frag ? frag_index(e_row, e_col, p.N >> 4) : (size_t)e_row * p.ldy + e_col;
-    if (p.ksb > 1) e_addr = ((size_t)blockIdx.y * p.rows + e_row) * p.N + e_col;
+    if (p.ksb > 1 && !p.cnt) e_addr = ((size_t)blockIdx.y * p.rows + e_row) * p.N + e_col;
     if (p.bias) e_bias = p.bias[e_col];
     if (ln) e_u = p.colsum[e_col];
     if (p.res) e_res = p.res[e_addr];
@@ -382,6 +384,36 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
   }
 
   // ---- fixed-order reduction over the K-slices and the epilogue: one output element per thread ----
+  if (p.ksb > 1 && p.cnt) {
+    // K split across workgroups, finished by whichever of them arrives last (wait-free: nobody spins).  Partial sums travel
+    // through agent-scope atomics (coherent across the XCDs' L2s); the sum runs in slab order, so the result does not depend
+    // on who is last.
+    __shared__ int s_last;
+    if (e_ok) {
+      float v = 0.f;
+      for (int w = 0; w < p.kw; ++w) v += redbuf[(w * NACC + e_t) * 256 + (tid & 255)];
+      if (WT == WFMT_FP8) v *= e_s;
+      __hip_atomic_store(&p.slab[((size_t)blockIdx.y * p.rows + e_row) * p.N + e_col], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // EVERY wave waits for the acknowledgement of its device-scope (sc1) stores before the workgroup barrier, so the arrival
+    // below is issued after all partial sums of this workgroup are at the device coherence point.  (An acq_rel arrival would
+    // say the same in the memory model, but costs an L2 write-back + invalidate per launch: measured +10 us.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(&p.cnt[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = old == (unsigned)p.ksb - 1u;
+      if (s_last) __hip_atomic_store(&p.cnt[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last || !e_ok) return;
+    float v = p.res ? e_res : 0.f;
+    v += e_bias;
+    for (int s = 0; s < p.ksb; ++s)
+      v += __hip_atomic_load(&p.slab[((size_t)s * p.rows + e_row) * p.N + e_col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    p.y[e_addr] = v;
+    return;
+  }
   if (e_t < NACC) {
     float v = 0.f;
     for (int w = 0; w < p.kw; ++w) v += redbuf[(w * NACC + e_t) * 256 + (tid & 255)];
@@ -459,7 +491,9 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
   int ntw = 1;
   gemv_fx_plan(w.N, w.K, a.rows, &ntw, &p.kw);
   p.ksb = a.ksb > 1 ? a.ksb : 1;
-  if (p.ksb > 1) IDX_CHECK(!a.colsum && !a.bias && !a.res && a.act == 0 && !a.y_frag, "a K-split launch writes raw partial sums");
+  p.slab = a.slab; p.cnt = p.ksb > 1 ? a.ksb_counters : nullptr;
+  if (p.ksb > 1 && !p.cnt) IDX_CHECK(!a.colsum && !a.bias && !a.res && a.act == 0 && !a.y_frag, "a K-split launch writes raw partial sums");
+  if (p.cnt) IDX_CHECK(a.slab && !a.colsum && a.act == 0, "fused K-split: slab, no folded LayerNorm, no activation");
   p.cps = cdiv(p.kc16, p.kw * p.ksb);
   p.act = a.act; p.dbg = a.dbg;
   const int MT = cdiv(a.rows, 16);
@@ -476,7 +510,7 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
     static bool attr_set = false;                                                                                         \
     if (!attr_set) {                                                                                                      \
       IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_fx_kernel<MTV, NTWV, SG, WTV>),                      \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                               \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));                               \
       attr_set = true;                                                                                                    \
     }                                                                                                                     \
     hipLaunchKernelGGL((gemv_fx_kernel<MTV, NTWV, SG, WTV>), grid, dim3(threads), lds, stream, p);                        \

@@ -12,6 +12,7 @@
 // decode_attn -> gemv16 c_proj -> rows_norm[LN2 ...] -> gemv16 c_fc -> gemv16 mlp.c_proj with fused
 // gelu_new on its input slab), + embedding, head and sampler; every per-step scalar is device-resident so the
 // whole step is captured once into a hipGraph and replayed per token (launch-bound otherwise).
+#include <cstdlib>
 #include <cstring>
 
 #include "gpt.h"
@@ -236,6 +237,7 @@ GPTModel::Buffers GPTModel::carve(void* ws, int B, int S, int max_new) const {
   b.finished = c.take<int>(B);
   b.cur_tok = c.take<int>(B);
   b.kstart = c.take<int>(B);
+  b.ksb_cnt = c.take<unsigned>((size_t)cdiv(d, 16));
   b.state = c.take<DecodeState>(1);
   b.bytes = (c.off + 255) & ~(size_t)255;
   return b;
@@ -332,10 +334,15 @@ int GPTModel::decode_step(const Buffers& w, int B, float penalty, long long* cod
     GemvFXArgs fb;      // x += mlp.c_proj(ff) + b
     fb.xf = w.ffd; fb.rows = B;
     const int ksb = gemv_fx_ksb(L.fc2_g.N, L.fc2_g.K);
-    if (ksb > 1) {      // K split across workgroups (all 256 CUs stream), partial sums combined in a fixed order
+    static const bool unfused = getenv("IDXTTS_FX_UNFUSED") != nullptr;
+    if (ksb > 1 && unfused) {      // K split across workgroups (all 256 CUs stream), partial sums combined in a fixed order
       fb.ksb = ksb; fb.y = w.slab; fb.ldy = d;
       if (gemv_fx_forward(L.fc2_g, fb, st)) return 1;
       if (gemv_fx_combine(w.slab, ksb, B, d, L.fc2_l.bias, w.xd, w.xd, st)) return 1;
+    } else if (ksb > 1) {          // ... by the last workgroup of each column tile to arrive (no combine launch)
+      fb.ksb = ksb; fb.slab = w.slab; fb.ksb_counters = w.ksb_cnt;
+      fb.bias = L.fc2_l.bias; fb.res = w.xd; fb.y = w.xd; fb.y_frag = 1;
+      if (gemv_fx_forward(L.fc2_g, fb, st)) return 1;
     } else {
       fb.bias = L.fc2_l.bias; fb.res = w.xd; fb.y = w.xd; fb.y_frag = 1;
       if (gemv_fx_forward(L.fc2_g, fb, st)) return 1;
@@ -376,6 +383,7 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
   for (int b = 0; b < B; ++b) IDX_CHECK(kstart[b] >= 0 && kstart[b] < P, "pad_left out of range");
   IDX_HIP(hipMemcpyAsync(w.kstart, kstart.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
   IDX_HIP(hipMemsetAsync(w.finished, 0, B * sizeof(int), st));
+  IDX_HIP(hipMemsetAsync(w.ksb_cnt, 0, (size_t)cdiv(d, 16) * sizeof(unsigned), st));
   IDX_HIP(hipMemsetAsync(static_cast<char*>(ws) + w.frag_off, 0, w.frag_bytes, st));   // padding rows of the fragment images
   // input_ids of the reference = fake prefix of 1s + start_mel_token: both count for the repetition penalty
   std::vector<unsigned char> seen((size_t)B * V, 0);

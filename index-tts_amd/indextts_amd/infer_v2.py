@@ -82,31 +82,36 @@ class IndexTTS2:
     """
 
     def __init__(self, cfg_path="checkpoints/config.yaml", model_dir="checkpoints", use_fp16=False, device=None,
-                 use_cuda_kernel=None, use_deepspeed=False, use_accel=False, use_torch_compile=False):
-        if use_fp16:
-            warnings.warn("use_fp16 is ignored: the HIP path computes in float32 (parity with the CPU reference)")
+                 use_cuda_kernel=None, use_deepspeed=False, use_accel=False, use_torch_compile=False, gpt_weight_format=None):
+        # use_fp16 (reference: gpt.half() + fp16 autocast, infer_v2.py:109, 145-146) maps to bf16 STORAGE of the GPT weights:
+        # the arithmetic of the HIP path stays fp32.  gpt_weight_format ("f32" | "bf16" | "fp8") overrides it.
+        if gpt_weight_format is None:
+            gpt_weight_format = "bf16" if use_fp16 else "f32"
         need = [os.path.join(model_dir, f) for f in ("gpt.pth", "s2mel.pth")]
         missing = [p for p in need if not os.path.exists(p)]
         if missing:
             raise FileNotFoundError(f"IndexTTS-2 checkpoints not found ({missing}); use IndexTTS2.from_state_dicts(...)")
         from .checkpoint import load_reference_checkpoints
         gpt_sd, s2mel_sd, voc_sd = load_reference_checkpoints(model_dir)
-        self._init(PipelineConfig(), gpt_sd, s2mel_sd, voc_sd, device)
+        self._init(PipelineConfig(), gpt_sd, s2mel_sd, voc_sd, device, gpt_weight_format)
 
     @classmethod
-    def from_state_dicts(cls, cfg: PipelineConfig, gpt_sd, s2mel_sd, bigvgan_sd, device=None) -> "IndexTTS2":
+    def from_state_dicts(cls, cfg: PipelineConfig, gpt_sd, s2mel_sd, bigvgan_sd, device=None, gpt_weight_format="f32",
+                         keep_effective_gpt=False) -> "IndexTTS2":
+        """gpt_weight_format: "f32" | "bf16" | "fp8" storage of the GPT linear weights (UnifiedVoice); keep_effective_gpt keeps
+        `self.gpt.effective_state_dict` (the rounded model, reference keys) for parity checks."""
         self = cls.__new__(cls)
-        self._init(cfg, gpt_sd, s2mel_sd, bigvgan_sd, device)
+        self._init(cfg, gpt_sd, s2mel_sd, bigvgan_sd, device, gpt_weight_format, keep_effective_gpt)
         return self
 
-    def _init(self, cfg, gpt_sd, s2mel_sd, bigvgan_sd, device):
+    def _init(self, cfg, gpt_sd, s2mel_sd, bigvgan_sd, device, gpt_weight_format="f32", keep_effective_gpt=False):
         if device is None:
             device = f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cpu"
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("IndexTTS2 (HIP path) needs an MI355X device; there is no CPU fallback")
         self.cfg = cfg
-        self.gpt = UnifiedVoice(gpt_sd, cfg.gpt, device=self.device)
+        self.gpt = UnifiedVoice(gpt_sd, cfg.gpt, device=self.device, weight_format=gpt_weight_format, keep_effective=keep_effective_gpt)
         self.s2mel = S2Mel(s2mel_sd, cfg.s2mel, device=self.device)
         self.bigvgan = BigVGAN(bigvgan_sd, cfg.bigvgan)
         self.stop_mel_token = cfg.gpt.stop_mel_token
