@@ -224,13 +224,13 @@ template <> struct WRaw<WFMT_FP8> {
 template <int MT, int NTW, bool SINGLE, int WT>
 __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
   typedef typename WRaw<WT>::raw wraw_t;
+  if (p.dbg & 8) return;      // tools/gemv_probe.hip: launch + dispatch cost of this geometry alone
   constexpr int UN = FXCfg<MT, NTW, SINGLE>::UN;
   constexpr int NB = SINGLE ? 1 : 2;
   constexpr int NACC = MT * NTW;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* redbuf = sm;                               // [kw][NACC][256]
   float* wstat = sm + p.kw * NACC * 256;            // [kw][MT*16][2]  per K-slice: mean, M2 (count is known)
-  float* rstat = wstat + p.kw * MT * 32;            // [MT*16][2]      mean, rstd
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nt0 = blockIdx.x * NTW;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int j = 0; j < NTW; ++j) *reinterpret_cast<f32x4*>(&redbuf[((wave * NACC + mt * NTW + j) * 64 + lane) * 4]) = acc[mt][j];
-  if (ln && kwave) {
+  if (ln && kwave && !(p.dbg & 16)) {
     // the four lane groups (lane >> 4) hold disjoint k of the same row: fold them, then slice mean / M2 about the mean
     const float cnt = 16.0f * nch;    // K-slice elements per row (padded chunks excluded: K % 16 == 0 for folded layers)
 #pragma unroll
@@ -365,22 +365,26 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
     }
   }
   __syncthreads();
-  if (ln) {
-    if (tid < MT * 16) {     // Chan / Welford pairwise update over the K-slices, fixed order
-      float n = 0.f, mean = 0.f, m2 = 0.f;
-      for (int w = 0; w < p.kw; ++w) {
-        const float nw = 16.0f * max(0, min(p.cps, p.kc16 - w * p.cps));      // (folded LayerNorm implies ksb == 1)
-        if (nw == 0.f) continue;
-        const float mw = wstat[(w * MT * 16 + tid) * 2], qw = wstat[(w * MT * 16 + tid) * 2 + 1];
-        const float dlt = mw - mean, nn = n + nw;
-        mean += dlt * (nw / nn);
-        m2 += qw + dlt * dlt * (n * nw / nn);
-        n = nn;
-      }
-      rstat[tid * 2] = mean;
-      rstat[tid * 2 + 1] = rsqrtf(m2 / n + p.ln_eps);
-    }
-    __syncthreads();
+  // Row statistics of the folded LayerNorm, combined per WAVE for the 4 rows its 64 epilogue threads own (no serial pass, no
+  // second barrier): lane j holds K-slice (j >> 2) of its own row (row = ... + (j & 3), see e_row), an xor butterfly over the
+  // slice bits adds them -- the same tree in every lane, so all lanes of a row agree bit for bit -- with the exact identity
+  //   mean = sum_w n_w mean_w / n,   M2 = sum_w M2_w + sum_w n_w (mean_w - mean)^2
+  float ln_mean = 0.f, ln_rstd = 0.f;
+  if (ln && e_t < NACC && !(p.dbg & 32)) {      // wave-uniform (e_t = tid >> 8); rows beyond p.rows are zero padding: harmless
+    const int sl = lane >> 2;
+    const bool on = sl < p.kw;
+    const float nw = on ? 16.0f * max(0, min(p.cps, p.kc16 - sl * p.cps)) : 0.f;      // (folded LayerNorm implies ksb == 1)
+    const int srow = e_mt * 16 + (e_ln >> 4) * 4 + e_r;
+    const float2 st = on ? *reinterpret_cast<const float2*>(&wstat[(sl * MT * 16 + srow) * 2]) : make_float2(0.f, 0.f);
+    float n = nw, a = nw * st.x;
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) { n += __shfl_xor(n, m); a += __shfl_xor(a, m); }
+    ln_mean = a / n;
+    const float dlt = st.x - ln_mean;
+    float m2 = st.y + nw * dlt * dlt;
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) m2 += __shfl_xor(m2, m);
+    ln_rstd = rsqrtf(m2 / n + p.ln_eps);
   }
 
   // ---- fixed-order reduction over the K-slices and the epilogue: one output element per thread ----
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
     for (int w = 0; w < p.kw; ++w) v += redbuf[(w * NACC + e_t) * 256 + (tid & 255)];
     if (e_ok) {
       if (WT == WFMT_FP8) v *= e_s;        // power-of-two column scale: exact
-      if (ln) v = rstat[e_row * 2 + 1] * (v - rstat[e_row * 2] * e_u);
+      if (ln) v = ln_rstd * (v - ln_mean * e_u);
       v += e_bias;
       if (p.act == 1) v = gelu_new_fx(v);
       if (p.res) v += e_res;
