@@ -19,7 +19,14 @@ struct DecodeAttnArgs {
   const DecodeState* st = nullptr;
   int B = 0, H = 0, Smax = 0, d = 0;
   float scale = 0.125f;
+  // Key split for small batches (B * H workgroups cannot pull the KV stream through 256 CUs: a CU sustains ~25 GB/s):
+  // nsplit > 1 workgroups per (utterance, head) each take a contiguous range of the keys and leave (max, sum, unnormalised
+  // output); the last one to arrive merges them in split order (wait-free, decode_attn_nsplit() depends on B and H only).
+  int nsplit = 1;
+  float* part = nullptr;        // [B][H][nsplit][66]
+  unsigned* cnt = nullptr;      // [B][H] arrival counters: 0 on entry, left at 0
 };
+int decode_attn_nsplit(int B, int H);
 int decode_attn_forward(const DecodeAttnArgs& a, hipStream_t stream);
 
 struct SampleArgs {

@@ -13,6 +13,9 @@
 // KV cache layout (chosen for the decode read pattern, the only hot reader):
 //   K: [B][H][16][Smax][4]   dot products walk the keys with lanes = keys -> 16-byte, fully coalesced
 //   V: [B][H][Smax][64]      P.V walks the keys with lanes = head dim    -> 256-byte coalesced rows
+#include <algorithm>
+#include <cstdlib>
+
 #include "decode.h"
 #include "prof.h"
 
@@ -47,18 +50,23 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
   // Everything that does not depend on the new token's q is put in flight first: this thread's first key (16 x 16 B,
   // coalesced across threads) and its first 8 value rows of the P.V phase; the kernel is a chain of dependent
   // HBM / L2 round trips, so the cache streams have to overlap the qkv fetch and the softmax barriers.
-  const int ks = p.kstart ? p.kstart[b] : 0;
+  // key range of this workgroup: all of [kstart, pos] (pos = the new token), or one of gridDim.z contiguous pieces of it
+  const int ks0 = p.kstart ? p.kstart[b] : 0;
+  const int NS = gridDim.z, z = blockIdx.z;
+  const int chunk = NS > 1 ? (((pos - ks0 + NS) / NS + 15) & ~15) : pos - ks0 + 1;
+  const int ks = ks0 + z * chunk;
+  const int ke = min(pos, ks + chunk - 1);          // inclusive; ks > ke: an empty piece
   const int grp = tid >> 4, l16 = tid & 15;
   const int s_first = ks + tid;
   f32x4 kk0[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i)
-    kk0[i] = s_first < pos ? *reinterpret_cast<const f32x4*>(kc + ((size_t)i * Smax + s_first) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    kk0[i] = (s_first < pos && s_first <= ke) ? *reinterpret_cast<const f32x4*>(kc + ((size_t)i * Smax + s_first) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 vpre[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int sj = ks + grp + 16 * j;
-    vpre[j] = sj < pos ? *reinterpret_cast<const f32x4*>(vc + (size_t)sj * 64 + 4 * l16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    vpre[j] = (sj < pos && sj <= ke) ? *reinterpret_cast<const f32x4*>(vc + (size_t)sj * 64 + 4 * l16) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
   // ---- q, k, v of the new token (waves 0,1,2 take q,k,v) ----
@@ -70,8 +78,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
     float acc = p.qkv_bias ? p.qkv_bias[col] : 0.0f;
     for (int s = 0; s < p.parts; ++s) acc += row[(size_t)s * sst];
     if (which == 0) qs[dd] = acc * p.scale;
-    else if (which == 1) { knew[dd] = acc; kc[((size_t)(dd >> 2) * Smax + pos) * 4 + (dd & 3)] = acc; }
-    else { vnew[dd] = acc; vc[(size_t)pos * 64 + dd] = acc; }
+    else if (which == 1) { knew[dd] = acc; if (z == 0) kc[((size_t)(dd >> 2) * Smax + pos) * 4 + (dd & 3)] = acc; }
+    else { vnew[dd] = acc; if (z == 0) vc[(size_t)pos * 64 + dd] = acc; }
   }
   __syncthreads();
 
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
 
   // ---- scores: one key per thread ----
   float mx = -1e30f;
-  for (int s = s_first; s <= pos; s += 256) {
+  for (int s = s_first; s <= ke; s += 256) {
     float dot = 0.f;
     if (s == pos) {
 #pragma unroll
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float sum = 0.f;
-  for (int s = s_first; s <= pos; s += 256) {
+  for (int s = s_first; s <= ke; s += 256) {
     const float e = expf(pr[s] - mx);
     pr[s] = e;
     sum += e;
@@ -124,12 +132,12 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int sj = ks + grp + 16 * j;
-    if (sj <= pos) {
+    if (sj <= ke) {
       const f32x4 t = pr[sj] * (sj == pos ? vn4 : vpre[j]);
       if ((j & 3) == 0) a0 += t; else if ((j & 3) == 1) a1 += t; else if ((j & 3) == 2) a2 += t; else a3 += t;
     }
   }
-  for (int sb = ks + grp + 128; sb <= pos; sb += 128) {
+  for (int sb = ks + grp + 128; sb <= ke; sb += 128) {
     f32x4 v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int sj = sb + 16 * j;
-      if (sj <= pos) {
+      if (sj <= ke) {
         const f32x4 t = pr[sj] * v[j];
         if ((j & 3) == 0) a0 += t; else if ((j & 3) == 1) a1 += t; else if ((j & 3) == 2) a2 += t; else a3 += t;
       }
@@ -147,27 +155,73 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
   }
   *reinterpret_cast<f32x4*>(&outp[grp * 64 + 4 * l16]) = (a0 + a1) + (a2 + a3);
   __syncthreads();
+  float o = 0.f;
   if (tid < 64) {
-    float o = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) o += outp[g * 64 + tid];
-    p.out[frag_index(b, h * 64 + tid, d >> 4)] = l > 0.f ? o / l : 0.f;     // A-fragment image for the c_proj GEMV
   }
+  if (NS == 1) {
+    if (tid < 64) p.out[frag_index(b, h * 64 + tid, d >> 4)] = l > 0.f ? o / l : 0.f;     // A-fragment image for the c_proj GEMV
+    return;
+  }
+  // ---- key split: leave (o, max, sum) of this piece; the last piece to arrive merges all of them in piece order ----
+  __shared__ int s_last;
+  float* mine = p.part + ((size_t)(b * p.H + h) * NS + z) * 66;
+  if (tid < 64) __hip_atomic_store(&mine[tid], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 64) __hip_atomic_store(&mine[64], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 65) __hip_atomic_store(&mine[65], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // device-scope stores acknowledged before the arrival (see gemv_fx.hip)
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(&p.cnt[b * p.H + h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = old == (unsigned)NS - 1u;
+    if (s_last) __hip_atomic_store(&p.cnt[b * p.H + h], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last || tid >= 64) return;
+  const float* all = p.part + (size_t)(b * p.H + h) * NS * 66;
+  float mi[16], li[16], oi[16];       // every piece's (max, sum, this lane's output) in ONE round trip
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const bool on = i < NS;
+    mi[i] = on ? __hip_atomic_load(&all[i * 66 + 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1e30f;
+    li[i] = on ? __hip_atomic_load(&all[i * 66 + 65], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+    oi[i] = on ? __hip_atomic_load(&all[i * 66 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+  }
+  float M = -1e30f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) M = fmaxf(M, mi[i]);
+  float O = 0.f, L = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float wgt = li[i] > 0.f ? expf(mi[i] - M) : 0.f;
+    O += wgt * oi[i];
+    L += wgt * li[i];
+  }
+  p.out[frag_index(b, h * 64 + tid, d >> 4)] = L > 0.f ? O / L : 0.f;
+}
+
+int decode_attn_nsplit(int B, int H) {
+  static const int forced = getenv("IDXTTS_ATTN_SPLIT") ? atoi(getenv("IDXTTS_ATTN_SPLIT")) : 0;
+  if (forced > 0) return std::min(forced, 16);
+  const int wgs = B * H;
+  return wgs <= 128 ? std::max(1, std::min(16, 256 / wgs)) : 1;
 }
 
 int decode_attn_forward(const DecodeAttnArgs& a, hipStream_t stream) {
   IDX_CHECK(a.qkv_part && a.kcache && a.vcache && a.out && a.st, "null pointer");
   IDX_CHECK(a.d == a.H * 64, "head_dim must be 64");
   const size_t lds = (size_t)(256 + 1024 + a.Smax) * sizeof(float);
-  IDX_CHECK(lds <= 160 * 1024, "Smax too large for the LDS score buffer");
+  IDX_CHECK(lds <= 128 * 1024, "Smax too large for the LDS score buffer");
   static bool attr_set = false;
   if (!attr_set) {
-    IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     attr_set = true;
   }
+  IDX_CHECK(a.nsplit >= 1 && a.nsplit <= 16 && (a.nsplit == 1 || (a.part && a.cnt)), "key split: 1..16 pieces, partial buffer and counters");
   // algorithmic bytes depend on the device-side position; the caller (bench) accounts for them
   ProfScope prof(PROF_DECODE_ATTN, stream, 0.0, 0.0);
-  hipLaunchKernelGGL(decode_attn_kernel, dim3(a.H, a.B), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(decode_attn_kernel, dim3(a.H, a.B, a.nsplit), dim3(256), lds, stream, a);
   IDX_LAUNCH_CHECK();
   return 0;
 }

@@ -411,10 +411,14 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
     }
     __syncthreads();
     if (!s_last || !e_ok) return;
+    float t[8];      // all partial sums in ONE round trip (a loop of atomic loads is issued one after the other)
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      t[s] = s < p.ksb ? __hip_atomic_load(&p.slab[((size_t)s * p.rows + e_row) * p.N + e_col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
     float v = p.res ? e_res : 0.f;
     v += e_bias;
-    for (int s = 0; s < p.ksb; ++s)
-      v += __hip_atomic_load(&p.slab[((size_t)s * p.rows + e_row) * p.N + e_col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) v += t[s];
     p.y[e_addr] = v;
     return;
   }
@@ -497,7 +501,7 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
   p.ksb = a.ksb > 1 ? a.ksb : 1;
   p.slab = a.slab; p.cnt = p.ksb > 1 ? a.ksb_counters : nullptr;
   if (p.ksb > 1 && !p.cnt) IDX_CHECK(!a.colsum && !a.bias && !a.res && a.act == 0 && !a.y_frag, "a K-split launch writes raw partial sums");
-  if (p.cnt) IDX_CHECK(a.slab && !a.colsum && a.act == 0, "fused K-split: slab, no folded LayerNorm, no activation");
+  if (p.cnt) IDX_CHECK(a.slab && !a.colsum && a.act == 0 && p.ksb <= 8, "fused K-split: slab, no folded LayerNorm, no activation, <= 8 pieces");
   p.cps = cdiv(p.kc16, p.kw * p.ksb);
   p.act = a.act; p.dbg = a.dbg;
   const int MT = cdiv(a.rows, 16);

@@ -36,6 +36,7 @@ struct GPTModel : ModelBase {
     float *qkvd, *logits, *slab;              // [B][3d], [B][V] row-major; [<=8][B][d] K-split partial sums of mlp.c_proj
     size_t frag_off, frag_bytes;              // the fragment-image region (zeroed once per generate: padding rows stay 0)
     unsigned char* seen; int *finished, *cur_tok, *kstart;
+    float* attn_part; unsigned* attn_cnt;     // key-split decode attention: [B][H][<=16][66] partials, [B][H] counters
     unsigned* ksb_cnt;                        // [d/16] arrival counters of the fused K-split mlp.c_proj (zeroed per generate)
     DecodeState* state;
     size_t bytes;

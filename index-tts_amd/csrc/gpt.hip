@@ -238,6 +238,8 @@ GPTModel::Buffers GPTModel::carve(void* ws, int B, int S, int max_new) const {
   b.cur_tok = c.take<int>(B);
   b.kstart = c.take<int>(B);
   b.ksb_cnt = c.take<unsigned>((size_t)cdiv(d, 16));
+  b.attn_cnt = c.take<unsigned>((size_t)B * cfg.heads);
+  b.attn_part = c.take<float>((size_t)B * cfg.heads * 16 * 66);
   b.state = c.take<DecodeState>(1);
   b.bytes = (c.off + 255) & ~(size_t)255;
   return b;
@@ -324,6 +326,7 @@ int GPTModel::decode_step(const Buffers& w, int B, float penalty, long long* cod
     da.qkv_part = w.qkvd; da.parts = 1; da.part_rows = B; da.qkv_bias = nullptr;
     da.kcache = w.kcache + li * per_layer; da.vcache = w.vcache + li * per_layer; da.out = w.attd; da.kstart = w.kstart;
     da.st = w.state; da.B = B; da.H = cfg.heads; da.Smax = w.Smax; da.d = d; da.scale = 0.125f;
+    da.nsplit = decode_attn_nsplit(B, cfg.heads); da.part = w.attn_part; da.cnt = w.attn_cnt;
     if (decode_attn_forward(da, st)) return 1;
     GemvFXArgs pa;      // x += c_proj(attn) + b  (in place: a thread reads and writes only its own element of x)
     pa.xf = w.attd; pa.rows = B; pa.bias = L.proj_l.bias; pa.res = w.xd; pa.y = w.xd; pa.y_frag = 1;
@@ -384,6 +387,7 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
   IDX_HIP(hipMemcpyAsync(w.kstart, kstart.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
   IDX_HIP(hipMemsetAsync(w.finished, 0, B * sizeof(int), st));
   IDX_HIP(hipMemsetAsync(w.ksb_cnt, 0, (size_t)cdiv(d, 16) * sizeof(unsigned), st));
+  IDX_HIP(hipMemsetAsync(w.attn_cnt, 0, (size_t)B * cfg.heads * sizeof(unsigned), st));
   IDX_HIP(hipMemsetAsync(static_cast<char*>(ws) + w.frag_off, 0, w.frag_bytes, st));   // padding rows of the fragment images
   // input_ids of the reference = fake prefix of 1s + start_mel_token: both count for the repetition penalty
   std::vector<unsigned char> seen((size_t)B * V, 0);

@@ -259,6 +259,25 @@ def test_greedy_batch_above_16_rows_vs_oracle(device):
     assert np.array_equal(codes.cpu().numpy(), ref.numpy())
 
 
+def test_greedy_48_rows_unsplit_attention_vs_oracle(device):
+    """B x heads > 128 workgroups: the decode attention runs one workgroup per (utterance, head) (smaller batches split the
+    keys of each head over several workgroups, which every other test here exercises); three row tiles in the GEMVs."""
+    from indextts_amd.gpt import UnifiedVoice
+    from oracle import gpt as og
+    cfg = GPTConfig(model_dim=256, heads=4, layers=2, number_text_tokens=300, number_mel_codes=258, start_mel_token=256,
+                    stop_mel_token=257, max_mel_tokens=40, max_text_tokens=30, cond_latents=6)
+    w = weights.synth_gpt_weights(cfg, tag="t/gpt/b48")
+    uv = UnifiedVoice(w, cfg, device=device)
+    tw = {k: torch.from_numpy(v) for k, v in w.items()}
+    B, L = 48, 7
+    lat = torch.from_numpy(synth.uniform("t/gpt/b48/lat", (B, cfg.cond_latents, cfg.model_dim), 0.5))
+    emo = torch.from_numpy(synth.uniform("t/gpt/b48/emo", (B, cfg.model_dim), 0.3))
+    text = torch.from_numpy(synth.integers("t/gpt/b48/text", (B, L), 2, cfg.number_text_tokens))
+    codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=10, repetition_penalty=10.0)
+    ref = og.generate_greedy(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, 10, 10.0)
+    assert np.array_equal(codes.cpu().numpy(), ref.numpy())
+
+
 def test_greedy_wide_mlp_k_split_vs_oracle(device):
     """model_dim 256: mlp.c_proj has K = 1024, the shape class whose decode GEMV is split across workgroups
     (partial-sum slab + fixed-order combine, gemv_fx_ksb); codes must still equal the oracle's."""
