@@ -147,7 +147,15 @@ def build_pipeline(args, world, rank, dev):
     wv = weights.synth_bigvgan_weights(cfg.bigvgan, tag="bench/bigvgan")
     log(f"[bench] rank {rank}: synthetic weights in {time.time() - t0:.1f}s")
     compact = args.gpt_weights != "f32"
-    tts = IndexTTS2.from_state_dicts(cfg, wg, ws, wv, device=dev, gpt_weight_format=args.gpt_weights,
+    ws_gpu = ws
+    if os.environ.get("IDXTTS_EXP_S2MEL_BF16"):      # experiment: what would bf16-rounded s2mel weights cost in mel L1?
+        def r16(a):
+            u = a.view(np.uint32).astype(np.uint64)
+            u = ((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32)
+            return u.view(np.float32)
+        ws_gpu = {k: (r16(np.ascontiguousarray(v, dtype=np.float32)) if v.ndim >= 2 else v) for k, v in ws.items()}
+        log("[bench] EXPERIMENT: s2mel matrices rounded to bf16 on the GPU side only")
+    tts = IndexTTS2.from_state_dicts(cfg, wg, ws_gpu, wv, device=dev, gpt_weight_format=args.gpt_weights,
                                      keep_effective_gpt=compact and rank == 0 and not args.no_cpu_baseline)
     if tts.gpt.effective_state_dict is not None:      # the CPU leg runs the SAME (rounded) model the kernels run
         wg = tts.gpt.effective_state_dict
