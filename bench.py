@@ -45,7 +45,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def roofline_from_profile(prof, steps, workload="pipeline", split_bf16=True):
+def roofline_from_profile(prof, steps, workload="pipeline", split_bf16=True, default_config=True):
     tot_ms = sum(v["ms"] for v in prof.values())
     for name, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
         log(f"[bench] kernel {name:22s} launches/step {v['launches'] // steps:6d}  {v['ms'] / steps:9.3f} ms/step "
@@ -72,7 +72,7 @@ def roofline_from_profile(prof, steps, workload="pipeline", split_bf16=True):
     try:
         with open(os.path.join(ROOT, "profiles", "traffic_r01.json")) as f:
             tr = json.load(f)["kernels"].get(dom_name)
-        if tr and workload == "pipeline":
+        if tr and workload == "pipeline" and default_config:      # the PMC passes on file are of the default configs[2] command
             r["traffic"] = tr["hbm_bytes_per_launch"]
             r["traffic_source"] = "profiles/traffic_r01.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes = (2*FETCH+WRITE)*1024)"
     except (OSError, KeyError, ValueError):
@@ -304,7 +304,9 @@ def main() -> int:
         torch.cuda.synchronize()
         prof = _lib.profile_read()
         _lib.profile_enable(False)
-        roofline = roofline_from_profile(prof, nprof, args.workload, split_bf16=args.gemm != "f32")
+        default_cfg = (not args.longform and args.gpt_weights == "f32" and args.gemm == "bf16x3" and (args.batch or 16) == 16
+                       and args.codes == 512 and args.text_tokens == 128 and args.prompt_frames == 689)
+        roofline = roofline_from_profile(prof, nprof, args.workload, split_bf16=args.gemm != "f32", default_config=default_cfg)
         if stage_times_fn is not None:   # device-synchronised timers behind the reference's four stage names (infer_v2.py:895-901)
             stages = {k: round(v, 4) for k, v in stage_times_fn().items()}
             log(f"[bench] stage seconds (synchronised, one step): {stages}")
