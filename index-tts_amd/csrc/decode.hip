@@ -32,14 +32,18 @@ __device__ __forceinline__ float wave_add(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p) {
+// NT threads per workgroup: NT / 16 key groups in the P.V phase, NT keys per pass of the score phase.  512 threads at <= 128
+// VGPRs (two workgroups per CU) halve the number of dependent load -> use passes of the 256-thread form.
+template <int NT>
+__global__ __launch_bounds__(NT, (NT == 512 ? 4 : 1)) void decode_attn_kernel(const DecodeAttnArgs p) {
+  constexpr int NW = NT / 64, NG = NT / 16;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* qs = sm;            // [64] scaled query
   float* knew = sm + 64;     // [64]
   float* vnew = sm + 128;    // [64]
-  float* red = sm + 192;     // [8]
-  float* outp = sm + 256;    // [16][64] per-key-group partial outputs
-  float* pr = sm + 256 + 1024;   // [Smax] scores / probabilities
+  float* red = sm + 192;     // [2 * NW]
+  float* outp = sm + 256;    // [NG][64] per-key-group partial outputs
+  float* pr = sm + 256 + NG * 64;   // [Smax] scores / probabilities
 
   const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int pos = p.st->pos;                  // index of the token being processed = keys already cached
@@ -62,10 +66,11 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
 #pragma unroll
   for (int i = 0; i < 16; ++i)
     kk0[i] = (s_first < pos && s_first <= ke) ? *reinterpret_cast<const f32x4*>(kc + ((size_t)i * Smax + s_first) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 vpre[8];
+  constexpr int VP = NT == 512 ? 4 : 8;      // value rows prefetched per lane before the scores (NG * VP = 128 keys either way)
+  f32x4 vpre[VP];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int sj = ks + grp + 16 * j;
+  for (int j = 0; j < VP; ++j) {
+    const int sj = ks + grp + NG * j;
     vpre[j] = (sj < pos && sj <= ke) ? *reinterpret_cast<const f32x4*>(vc + (size_t)sj * 64 + 4 * l16) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
@@ -83,29 +88,37 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
   }
   __syncthreads();
 
-  f32x4 q4[16];
+  // the query is wave-uniform: 64 SGPRs (v_readlane of one LDS read per lane) instead of 64 VGPRs
+  const float qlane = qs[lane];
+  float qv[64];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) q4[i] = *reinterpret_cast<const f32x4*>(&qs[4 * i]);
+  for (int i = 0; i < 64; ++i) qv[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qlane), i));
 
-  // ---- scores: one key per thread ----
+  // ---- scores: one key per thread and pass; the first pass consumes the prefetched key ----
   float mx = -1e30f;
-  for (int s = s_first; s <= ke; s += 256) {
+  if (s_first <= ke) {
+    float dot = 0.f;
+    if (s_first == pos) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dot += qv[4 * i] * knew[4 * i] + qv[4 * i + 1] * knew[4 * i + 1] + qv[4 * i + 2] * knew[4 * i + 2] + qv[4 * i + 3] * knew[4 * i + 3];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dot += qv[4 * i] * kk0[i][0] + qv[4 * i + 1] * kk0[i][1] + qv[4 * i + 2] * kk0[i][2] + qv[4 * i + 3] * kk0[i][3];
+    }
+    pr[s_first] = dot;
+    mx = dot;
+  }
+  for (int s = s_first + NT; s <= ke; s += NT) {
     float dot = 0.f;
     if (s == pos) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const f32x4 kk = *reinterpret_cast<const f32x4*>(&knew[4 * i]);
-        dot += q4[i][0] * kk[0] + q4[i][1] * kk[1] + q4[i][2] * kk[2] + q4[i][3] * kk[3];
-      }
-    } else if (s == s_first) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) dot += q4[i][0] * kk0[i][0] + q4[i][1] * kk0[i][1] + q4[i][2] * kk0[i][2] + q4[i][3] * kk0[i][3];
+      for (int i = 0; i < 16; ++i) dot += qv[4 * i] * knew[4 * i] + qv[4 * i + 1] * knew[4 * i + 1] + qv[4 * i + 2] * knew[4 * i + 2] + qv[4 * i + 3] * knew[4 * i + 3];
     } else {
       f32x4 kk[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) kk[i] = *reinterpret_cast<const f32x4*>(kc + ((size_t)i * Smax + s) * 4);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) dot += q4[i][0] * kk[i][0] + q4[i][1] * kk[i][1] + q4[i][2] * kk[i][2] + q4[i][3] * kk[i][3];
+      for (int i = 0; i < 16; ++i) dot += qv[4 * i] * kk[i][0] + qv[4 * i + 1] * kk[i][1] + qv[4 * i + 2] * kk[i][2] + qv[4 * i + 3] * kk[i][3];
     }
     pr[s] = dot;
     mx = fmaxf(mx, dot);
@@ -113,40 +126,44 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
   mx = wave_max(mx);
   if (lane == 0) red[wave] = mx;
   __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  mx = red[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w]);
   float sum = 0.f;
-  for (int s = s_first; s <= ke; s += 256) {
+  for (int s = s_first; s <= ke; s += NT) {
     const float e = expf(pr[s] - mx);
     pr[s] = e;
     sum += e;
   }
   sum = wave_add(sum);
-  if (lane == 0) red[4 + wave] = sum;
+  if (lane == 0) red[NW + wave] = sum;
   __syncthreads();
-  const float l = red[4] + red[5] + red[6] + red[7];
+  float l = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) l += red[NW + w];
 
   // ---- P.V : 16 key groups x 16 lanes; a lane owns 4 head dims (one 16-byte load per key, 256-byte rows coalesced),
   //      8 keys in flight per lane; group g takes keys ks+g, ks+g+16, ... ----
   const f32x4 vn4 = *reinterpret_cast<const f32x4*>(&vnew[4 * l16]);
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int sj = ks + grp + 16 * j;
+  for (int j = 0; j < VP; ++j) {
+    const int sj = ks + grp + NG * j;
     if (sj <= ke) {
       const f32x4 t = pr[sj] * (sj == pos ? vn4 : vpre[j]);
       if ((j & 3) == 0) a0 += t; else if ((j & 3) == 1) a1 += t; else if ((j & 3) == 2) a2 += t; else a3 += t;
     }
   }
-  for (int sb = ks + grp + 128; sb <= ke; sb += 128) {
+  for (int sb = ks + grp + VP * NG; sb <= ke; sb += 8 * NG) {
     f32x4 v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int sj = sb + 16 * j;
+      const int sj = sb + NG * j;
       v[j] = sj < pos ? *reinterpret_cast<const f32x4*>(vc + (size_t)sj * 64 + 4 * l16) : vn4;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int sj = sb + 16 * j;
+      const int sj = sb + NG * j;
       if (sj <= ke) {
         const f32x4 t = pr[sj] * v[j];
         if ((j & 3) == 0) a0 += t; else if ((j & 3) == 1) a1 += t; else if ((j & 3) == 2) a2 += t; else a3 += t;
@@ -158,7 +175,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs p
   float o = 0.f;
   if (tid < 64) {
 #pragma unroll
-    for (int g = 0; g < 16; ++g) o += outp[g * 64 + tid];
+    for (int g = 0; g < NG; ++g) o += outp[g * 64 + tid];
   }
   if (NS == 1) {
     if (tid < 64) p.out[frag_index(b, h * 64 + tid, d >> 4)] = l > 0.f ? o / l : 0.f;     // A-fragment image for the c_proj GEMV
@@ -211,17 +228,20 @@ int decode_attn_nsplit(int B, int H) {
 int decode_attn_forward(const DecodeAttnArgs& a, hipStream_t stream) {
   IDX_CHECK(a.qkv_part && a.kcache && a.vcache && a.out && a.st, "null pointer");
   IDX_CHECK(a.d == a.H * 64, "head_dim must be 64");
-  const size_t lds = (size_t)(256 + 1024 + a.Smax) * sizeof(float);
+  static const int nt = getenv("IDXTTS_ATTN_NT") ? atoi(getenv("IDXTTS_ATTN_NT")) : 512;
+  const size_t lds = (size_t)(256 + (nt / 16) * 64 + a.Smax) * sizeof(float);
   IDX_CHECK(lds <= 128 * 1024, "Smax too large for the LDS score buffer");
   static bool attr_set = false;
   if (!attr_set) {
-    IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_attn_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_attn_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     attr_set = true;
   }
   IDX_CHECK(a.nsplit >= 1 && a.nsplit <= 16 && (a.nsplit == 1 || (a.part && a.cnt)), "key split: 1..16 pieces, partial buffer and counters");
   // algorithmic bytes depend on the device-side position; the caller (bench) accounts for them
   ProfScope prof(PROF_DECODE_ATTN, stream, 0.0, 0.0);
-  hipLaunchKernelGGL(decode_attn_kernel, dim3(a.H, a.B, a.nsplit), dim3(256), lds, stream, a);
+  if (nt == 512) hipLaunchKernelGGL(decode_attn_kernel<512>, dim3(a.H, a.B, a.nsplit), dim3(512), lds, stream, a);
+  else hipLaunchKernelGGL(decode_attn_kernel<256>, dim3(a.H, a.B, a.nsplit), dim3(256), lds, stream, a);
   IDX_LAUNCH_CHECK();
   return 0;
 }
