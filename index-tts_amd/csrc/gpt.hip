@@ -8,10 +8,14 @@
 // Two weight copies are kept on purpose (288 GB HBM): an MFMA-32x32 packed copy for the GEMM-shaped
 // passes (prefill, latent: M = B*S rows) and a B-fragment stream-order copy for the M<=64 decode GEMVs.
 //
-// Decode step = 7 launches per layer (rows_norm[LN1 + residual + split-K combine] -> gemv16 c_attn ->
-// decode_attn -> gemv16 c_proj -> rows_norm[LN2 ...] -> gemv16 c_fc -> gemv16 mlp.c_proj with fused
-// gelu_new on its input slab), + embedding, head and sampler; every per-step scalar is device-resident so the
-// whole step is captured once into a hipGraph and replayed per token (launch-bound otherwise).
+// Decode step = 5 launches per layer, every activation an MFMA A-fragment image (gemv_fx.hip):
+//   c_attn [LayerNorm 1 folded in] -> decode_attn (+ KV-cache write) -> c_proj (+ residual, in place)
+//   -> c_fc [LayerNorm 2 folded in, gelu_new] -> mlp.c_proj (+ residual; K split over 4 workgroups per column tile, finished
+//   by the last one to arrive),
+// + embedding, final norms, head and sampler: 125 launches per token.  Every per-step scalar is device-resident, so the whole
+// step is captured once into a hipGraph and replayed per token (launch-bound otherwise).
+// The decode weight streams are fp32 by default; quantize_weights() rounds the model once to bf16 / fp8-e4m3 storage
+// (BASELINE configs[4]) -- the arithmetic stays the fp32 MFMA.
 #include <cstdlib>
 #include <cstring>
 
