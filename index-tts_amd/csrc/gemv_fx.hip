@@ -221,8 +221,13 @@ template <> struct WRaw<WFMT_FP8> {
   }
 };
 
-template <int MT, int NTW, bool SINGLE, int WT>
+// R4 (rows <= 4, MT == 1): the 16-block v_mfma_f32_4x4x1_16B_f32 instead of 16x16x4 -- a quarter of the MFMA cycles for the
+// same exact fp32 products.  Block b = lane >> 2 multiplies x[row r][k = 4 (b >> 2) + s] (lane 4 b + r) by
+// w[k][n = 4 (b & 3) + c] (lane 4 b + c): the weight stream is read as it is, the activation fragment is read from the lane
+// that holds row (lane & 3), and the accumulator ends up as the 16x16 C layout with the four k-groups (lane >> 4) still to add.
+template <int MT, int NTW, bool SINGLE, int WT, bool R4>
 __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
+  static_assert(!R4 || MT == 1, "the 4-row form has one row tile");
   typedef typename WRaw<WT>::raw wraw_t;
   if (p.dbg & 8) return;      // tools/gemv_probe.hip: launch + dispatch cost of this geometry alone
   constexpr int UN = FXCfg<MT, NTW, SINGLE>::UN;
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
   const wraw_t* wbase[NTW];      // one raw element = this lane's 4 weights of a chunk; 64 per chunk
 #pragma unroll
   for (int j = 0; j < NTW; ++j) wbase[j] = static_cast<const wraw_t*>(p.wp) + ((size_t)min(nt0 + j, p.ntiles - 1) * p.kc16 + c0) * 64 + lane;
-  const float* xbase = p.xf + (size_t)c0 * 256 + lane * 4;
+  const float* xbase = p.xf + (size_t)c0 * 256 + (R4 ? ((lane & 48) | (lane & 3)) : lane) * 4;
   const size_t ximg = (size_t)p.kc16 * 256;
 
   wraw_t wq[NB][UN][NTW];
@@ -319,7 +324,8 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int j = 0; j < NTW; ++j)
-              acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[buf][u][mt][s], wf[j][s], acc[mt][j], 0, 0, 0);
+              acc[mt][j] = R4 ? __builtin_amdgcn_mfma_f32_4x4x1f32(xq[buf][u][mt][s], wf[j][s], acc[mt][j], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_16x16x4f32(xq[buf][u][mt][s], wf[j][s], acc[mt][j], 0, 0, 0);
       }
     }
   };
@@ -339,6 +345,17 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
   if (p.dbg & 4) {
     if (acc[0][0][0] == 123.456f) p.y[tid] = acc[0][0][1];
     return;
+  }
+  if constexpr (R4) {      // add the four k-groups; lanes 0-15 then hold rows 0-3 exactly where the 16x16 layout has them
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[0][j][r];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        acc[0][j][r] = lane < 16 ? v : 0.f;
+      }
   }
 
   // ---- per-slice partial results to LDS (waves beyond kw exist only as epilogue threads) ----
@@ -513,15 +530,20 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
   const double flops = 2.0 * a.rows * (double)w.N * w.K;
   const double bytes = (double)wfmt_bytes(w.fmt) * w.N * w.K + 4.0 * ((double)a.rows * w.N * (a.res ? 2.0 : 1.0) + (double)a.rows * w.K);
   ProfScope prof(PROF_GEMV16, stream, flops, bytes);
-#define LAUNCH_W(MTV, NTWV, SG, WTV)                                                                                      \
+#define LAUNCH_R(MTV, NTWV, SG, WTV, R4V)                                                                                 \
   {                                                                                                                       \
     static bool attr_set = false;                                                                                         \
     if (!attr_set) {                                                                                                      \
-      IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_fx_kernel<MTV, NTWV, SG, WTV>),                      \
+      IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_fx_kernel<MTV, NTWV, SG, WTV, R4V>),                 \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));                               \
       attr_set = true;                                                                                                    \
     }                                                                                                                     \
-    hipLaunchKernelGGL((gemv_fx_kernel<MTV, NTWV, SG, WTV>), grid, dim3(threads), lds, stream, p);                        \
+    hipLaunchKernelGGL((gemv_fx_kernel<MTV, NTWV, SG, WTV, R4V>), grid, dim3(threads), lds, stream, p);                   \
+  }
+#define LAUNCH_W(MTV, NTWV, SG, WTV)                                                                                      \
+  {                                                                                                                       \
+    if (MTV == 1 && r4) LAUNCH_R(1, NTWV, SG, WTV, true)                                                                  \
+    else LAUNCH_R(MTV, NTWV, SG, WTV, false)                                                                              \
   }
 #define LAUNCH(MTV, NTWV, SG)                                                                                             \
   {                                                                                                                       \
@@ -529,12 +551,15 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
     else if (w.fmt == WFMT_BF16) LAUNCH_W(MTV, NTWV, SG, WFMT_BF16)                                                       \
     else LAUNCH_W(MTV, NTWV, SG, WFMT_F32)                                                                                \
   }
+  static const bool r4_on = !(getenv("IDXTTS_FX_R4") && atoi(getenv("IDXTTS_FX_R4")) == 0);
+  const bool r4 = r4_on && a.rows <= 4;
   const bool single = p.cps <= 5;
   if (MT == 1 && ntw == 2 && single) LAUNCH(1, 2, true)
   else if (MT == 1 && ntw == 2) LAUNCH(1, 2, false)
   else if (MT == 1 && single) LAUNCH(1, 1, true)
   else if (MT == 1) LAUNCH(1, 1, false)
   else if (MT == 2) LAUNCH(2, 1, false) else if (MT == 3) LAUNCH(3, 1, false) else LAUNCH(4, 1, false)
+#undef LAUNCH_R
 #undef LAUNCH_W
 #undef LAUNCH
   IDX_LAUNCH_CHECK();
