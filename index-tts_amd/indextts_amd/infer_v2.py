@@ -206,8 +206,26 @@ class IndexTTS2:
               use_emo_text=False, emo_text=None, use_random=False, interval_silence=200, verbose=False,
               max_text_tokens_per_segment=120, stream_return=False, more_segment_before=0, return_audio=False,
               return_numpy=False, **generation_kwargs):
-        """Reference signature (infer_v2.py:541-546).  On this path `spk_audio_prompt` must be a PromptConditioning and
-        `text` a list of token-id segments (List[List[int]]) or one segment (List[int] / 1-D tensor)."""
+        """Reference signature and return contract (infer_v2.py:541-567): the generator itself when `stream_return`, else its
+        first (only) item -- the output path, an InferenceResult, or (sampling_rate, int16 [n, 1]) -- or None for empty input.
+        On this path `spk_audio_prompt` must be a PromptConditioning and `text` a list of token-id segments
+        (List[List[int]]) or one segment (List[int] / 1-D tensor)."""
+        gen = self.infer_generator(spk_audio_prompt, text, output_path, emo_audio_prompt, emo_alpha, emo_vector, use_emo_text,
+                                   emo_text, use_random, interval_silence, verbose, max_text_tokens_per_segment, stream_return,
+                                   more_segment_before, return_audio=return_audio, return_numpy=return_numpy, **generation_kwargs)
+        if stream_return:
+            return gen
+        try:
+            return list(gen)[0]
+        except IndexError:
+            return None
+
+    def infer_generator(self, spk_audio_prompt, text, output_path, emo_audio_prompt=None, emo_alpha=1.0, emo_vector=None,
+                        use_emo_text=False, emo_text=None, use_random=False, interval_silence=200, verbose=False,
+                        max_text_tokens_per_segment=120, stream_return=False, quick_streaming_tokens=0, return_audio=False,
+                        return_numpy=False, **generation_kwargs):
+        """infer_v2.py:569-937.  Streaming (`stream_return`): after every segment yields its waveform (`[1, n]` float32 on the
+        CPU, already scaled and clamped to +-32767) and then the inter-segment silence, and nothing else (874-879, 885-886)."""
         if stream_return and return_audio:
             raise ValueError("stream_return and return_audio are mutually exclusive")                # infer_v2.py:575-576
         if not isinstance(spk_audio_prompt, PromptConditioning):
@@ -221,7 +239,7 @@ class IndexTTS2:
         segs = text if (len(text) and isinstance(text[0], (list, tuple, np.ndarray, torch.Tensor))) else [text]
         segs = [torch.as_tensor(s, dtype=torch.long).reshape(1, -1) for s in segs]
         if not segs or any(s.numel() == 0 for s in segs):
-            return None                                                                              # infer_v2.py:566-567
+            return                                                                                   # nothing yielded -> infer() returns None
         do_sample = generation_kwargs.pop("do_sample", False)
         num_beams = generation_kwargs.pop("num_beams", 1)
         if num_beams != 1:
@@ -238,12 +256,18 @@ class IndexTTS2:
             generation_kwargs.pop(k, None)
         start = time.perf_counter()
         wavs = []
+        sil = self.interval_silence(interval_silence=interval_silence)
         for s in segs:                                                                               # segment loop, infer_v2.py:732
             w = self.synthesize_batch(s, spk_audio_prompt, max_mel_tokens=max_mel_tokens, repetition_penalty=repetition_penalty,
                                       sampling=sampling)[0]
-            wavs.append(w)
+            if stream_return:                                                                        # infer_v2.py:874-879
+                yield w.cpu()
+                yield sil.cpu()
+            else:
+                wavs.append(w)
+        if stream_return:
+            return                                                                                   # infer_v2.py:885-886
         out = []
-        sil = self.interval_silence(interval_silence=interval_silence)
         for i, w in enumerate(wavs):                                                                 # insert_interval_silence 499-522
             out.append(w)
             if i + 1 < len(wavs):
@@ -260,8 +284,10 @@ class IndexTTS2:
             if os.path.dirname(output_path):
                 os.makedirs(os.path.dirname(output_path), exist_ok=True)
             write_wav_int16(output_path, mono.to(torch.int16).numpy(), sr)
-            return output_path                                                                       # infer_v2.py:917
+            yield output_path                                                                        # infer_v2.py:917
+            return
         if return_audio:
             audio = mono.clone()
-            return InferenceResult(sr, audio.numpy().copy() if return_numpy else audio, float(wav_length), saved, rtf)
-        return (sr, mono.unsqueeze(0).to(torch.int16).numpy().T)                                     # infer_v2.py:935-937
+            yield InferenceResult(sr, audio.numpy().copy() if return_numpy else audio, float(wav_length), saved, rtf)
+            return
+        yield (sr, mono.unsqueeze(0).to(torch.int16).numpy().T)                                      # infer_v2.py:935-937

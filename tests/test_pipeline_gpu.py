@@ -71,7 +71,7 @@ def test_infer_return_contract(device, tmp_path):
         assert f.getframerate() == 22050 and f.getnframes() == int(round(res.duration_sec * 22050))
     assert tts.infer(cond, [], None) is None
     with pytest.raises(ValueError):
-        tts.infer(cond, seg[0], None, stream_return=True, return_audio=True)
+        list(tts.infer(cond, seg[0], None, stream_return=True, return_audio=True))      # a generator: raises on first use, as the reference
     with pytest.raises(NotImplementedError):
         tts.infer("examples/voice_01.wav", seg[0], None)
     with pytest.raises(NotImplementedError):
@@ -84,3 +84,29 @@ def test_infer_return_contract(device, tmp_path):
     b = tts.infer(cond, seg[0], None, max_mel_tokens=16, do_sample=True, top_p=0.8, top_k=30, temperature=0.8, num_beams=1,
                   generator=torch.Generator().manual_seed(5))
     assert a[0] == 22050 and np.array_equal(a[1], b[1])
+
+
+def test_infer_streaming_contract(device):
+    """stream_return (infer_v2.py:547-555, 874-886): a generator that yields, per segment, the segment's waveform ([1, n] float32
+    on the CPU, scaled and clamped) and then the inter-segment silence -- and nothing else; joined, the chunks are the
+    non-streamed result plus the trailing silence."""
+    import types
+    cfg, wg, ws, wv, tts, cond = _build(device, eos_bias=6.5)
+    seg = synth.integers("t/pipe/stream", (3, 6), 2, cfg.gpt.number_text_tokens).tolist()
+    torch.manual_seed(11)
+    sr, whole = tts.infer(cond, seg, None, max_mel_tokens=16, interval_silence=100)
+    torch.manual_seed(11)
+    gen = tts.infer(cond, seg, None, max_mel_tokens=16, interval_silence=100, stream_return=True)
+    assert isinstance(gen, types.GeneratorType)
+    chunks = list(gen)
+    assert len(chunks) == 2 * len(seg)
+    n_sil = int(22050 * 100 / 1000.0)
+    for i, c in enumerate(chunks):
+        assert c.device.type == "cpu" and c.dtype == torch.float32 and c.ndim == 2 and c.shape[0] == 1
+        if i % 2:
+            assert c.shape[1] == n_sil and not c.any()
+        else:
+            assert c.shape[1] > 0 and c.abs().max() <= 32767.0
+    joined = torch.cat(chunks[:-1], dim=1).to(torch.int16).numpy().T
+    assert np.array_equal(joined, whole)
+    assert list(tts.infer(cond, [], None, stream_return=True)) == []
