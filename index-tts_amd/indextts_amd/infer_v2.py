@@ -120,16 +120,19 @@ class IndexTTS2:
         self._diffusion_steps = int(os.environ.get("TARS_DIFFUSION_STEPS", cfg.diffusion_steps))   # infer_v2.py:125
         self._cfg_rate = float(os.environ.get("TARS_CFG_RATE", cfg.cfg_rate))                      # infer_v2.py:126
         self.last_stage_times = {}
+        self.segment_batch = int(os.environ.get("IDXTTS_SEGMENT_BATCH", 16))      # segments of one infer() call synthesised together
 
     # ------------------------------------------------------------------------------------------
     def synthesize_batch(self, text_tokens: torch.Tensor, cond: PromptConditioning, max_mel_tokens: int = 1500,
                          repetition_penalty: float = 10.0, noise: Optional[torch.Tensor] = None, sync_timers: bool = False,
-                         return_intermediates: bool = False, sampling: Optional[dict] = None):
+                         return_intermediates: bool = False, sampling: Optional[dict] = None, per_row_noise: bool = False):
         """One batch of single-segment utterances sharing a prompt: the body of the reference's segment loop
         (infer_v2.py:732-881) for B rows at once.  text_tokens [B, L] (right-padded with stop_text_token).
         Returns a list of B waveforms, float32 [1, n_b] in int16 range (infer_v2.py:866).
         sampling: None = greedy; else the num_beams=1 sampling kwargs of UnifiedVoice.inference_speech
-        (do_sample, temperature, top_k, top_p, sampler, exp_noise / generator)."""
+        (do_sample, temperature, top_k, top_p, sampler, exp_noise / generator).
+        per_row_noise: draw the CFM noise row by row, `randn([1, 80, Tp + Tg_b])` in row order -- the draws the reference's
+        sequential segment loop makes (flow_matching.py:62 once per segment) -- instead of one [B, 80, T] draw."""
         dev = self.device
         c = cond.to(dev)
         B = text_tokens.shape[0]
@@ -172,7 +175,12 @@ class IndexTTS2:
         Tg = condv.shape[1]
         cat_condition = torch.cat([c.prompt_condition.expand(B, -1, -1), condv], dim=1)     # infer_v2.py:850
         x_lens = target_lens.cpu() + Tp
-        if noise is None:
+        if noise is None and per_row_noise and B > 1:
+            noise = torch.zeros([B, self.cfg.s2mel.in_channels, Tp + Tg], device=dev)
+            for b in range(B):
+                nb = int(x_lens[b])
+                noise[b, :, :nb] = torch.randn([1, self.cfg.s2mel.in_channels, nb], device=dev)[0]
+        elif noise is None:
             noise = torch.randn([B, self.cfg.s2mel.in_channels, Tp + Tg], device=dev)
         mel = self.s2mel.cfm_inference(cat_condition, x_lens, c.ref_mel.expand(B, -1, -1), c.style.expand(B, -1), None,
                                        self._diffusion_steps, inference_cfg_rate=self._cfg_rate, z=noise)
@@ -257,16 +265,27 @@ class IndexTTS2:
         start = time.perf_counter()
         wavs = []
         sil = self.interval_silence(interval_silence=interval_silence)
-        for s in segs:                                                                               # segment loop, infer_v2.py:732
-            w = self.synthesize_batch(s, spk_audio_prompt, max_mel_tokens=max_mel_tokens, repetition_penalty=repetition_penalty,
-                                      sampling=sampling)[0]
-            if stream_return:                                                                        # infer_v2.py:874-879
-                yield w.cpu()
-                yield sil.cpu()
-            else:
-                wavs.append(w)
         if stream_return:
+            for s in segs:                                                                           # segment loop, infer_v2.py:732
+                w = self.synthesize_batch(s, spk_audio_prompt, max_mel_tokens=max_mel_tokens, repetition_penalty=repetition_penalty,
+                                          sampling=sampling)[0]
+                yield w.cpu()                                                                        # infer_v2.py:874-879
+                yield sil.cpu()
             return                                                                                   # infer_v2.py:885-886
+        # Not streaming: the segments of one text are independent utterances of the same prompt, so they go through the
+        # batched path `segment_batch` at a time (one decode loop, one CFM solve, one ragged vocoder pass) instead of one by
+        # one; greedy codes are identical to the one-by-one flow, and the CFM noise is drawn segment by segment in order, so
+        # under a seed the waveforms agree with it to fp32 rounding.  segment_batch = 1 is the reference's loop as written.
+        nb = max(1, int(self.segment_batch))
+        stop_text = self.cfg.gpt.stop_text_token
+        for i in range(0, len(segs), nb):
+            grp = segs[i:i + nb]
+            L = max(s.shape[1] for s in grp)
+            toks = torch.full((len(grp), L), stop_text, dtype=torch.long)
+            for r, s in enumerate(grp):
+                toks[r, : s.shape[1]] = s[0]
+            wavs.extend(self.synthesize_batch(toks, spk_audio_prompt, max_mel_tokens=max_mel_tokens, repetition_penalty=repetition_penalty,
+                                              sampling=sampling, per_row_noise=True))
         out = []
         for i, w in enumerate(wavs):                                                                 # insert_interval_silence 499-522
             out.append(w)

@@ -108,5 +108,16 @@ def test_infer_streaming_contract(device):
         else:
             assert c.shape[1] > 0 and c.abs().max() <= 32767.0
     joined = torch.cat(chunks[:-1], dim=1).to(torch.int16).numpy().T
-    assert np.array_equal(joined, whole)
+    # non-streamed calls synthesise the segments as ONE ragged batch (same greedy codes, CFM noise drawn segment by segment in
+    # order): equal to the segment-by-segment stream up to fp32 rounding of the batched kernels
+    assert joined.shape == whole.shape
+    assert np.abs(joined.astype(np.int32) - whole.astype(np.int32)).max() <= 3
+    tts.segment_batch = 1                      # the reference's loop as written: bit for bit the streamed chunks
+    torch.manual_seed(11)
+    _, seq = tts.infer(cond, seg, None, max_mel_tokens=16, interval_silence=100)
+    assert np.array_equal(joined, seq)
+    tts.segment_batch = 2                      # 3 segments as a batch of 2 and a batch of 1
+    torch.manual_seed(11)
+    _, two = tts.infer(cond, seg, None, max_mel_tokens=16, interval_silence=100)
+    assert two.shape == whole.shape and np.abs(two.astype(np.int32) - whole.astype(np.int32)).max() <= 3
     assert list(tts.infer(cond, [], None, stream_return=True)) == []
