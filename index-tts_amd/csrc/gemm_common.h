@@ -23,6 +23,11 @@ struct GemmKP {
 };
 
 
+// Hardware-rate forms for the split-bf16 GEMM's fused gates (v_exp_f32 + v_rcp_f32, ~1 ulp each: absolute error < 2e-7, far below
+// the 2^-16 of the products they follow).  The exact-fp32 kernels keep libm (gemm_epilogue_t, act_apply).
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return fmaf(2.0f, sigmoid_fast(2.0f * x), -1.0f); }
+
 __device__ __forceinline__ float act_apply(float v, int act) {
   if (act == ACT_GELU_NEW) {
     const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
@@ -153,7 +158,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmKP& p, f32x16 (&acc)
         const f32x4 lin = *reinterpret_cast<const f32x4*>(src_off + rr * RS + 32) + b1;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          v[e] = p.act == ACT_SWIGLU ? (v[e] / (1.0f + expf(-v[e]))) * lin[e] : tanhf(v[e]) * (1.0f / (1.0f + expf(-lin[e])));
+          v[e] = p.act == ACT_SWIGLU ? (v[e] * sigmoid_fast(v[e])) * lin[e] : tanh_fast(v[e]) * sigmoid_fast(lin[e]);
       } else if (p.act != ACT_NONE) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act);
