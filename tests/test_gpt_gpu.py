@@ -457,3 +457,26 @@ def test_fp8_full_size_single_utterance_vs_oracle(device):
     with torch.no_grad():
         ref = og.generate_greedy(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, NEW, 10.0)
     assert np.array_equal(codes.cpu().numpy(), ref.numpy())
+
+
+def test_maximum_text_length_and_long_decode_vs_oracle(device):
+    """Edge of the position tables: a 600-token text (max_text_tokens) and several hundred generated codes on a narrow model, so
+    that the decode attention walks > 1024 cached keys (more than two passes of its score / P.V loops, and, with B = 2, key pieces
+    of > 64 keys per workgroup) -- greedy codes bit-exact against the oracle."""
+    from indextts_amd.gpt import UnifiedVoice
+    from oracle import gpt as og
+    cfg = GPTConfig(model_dim=128, heads=2, layers=2, number_mel_codes=130, number_text_tokens=90, start_mel_token=128, stop_mel_token=129,
+                    max_mel_tokens=1815, max_text_tokens=600, cond_latents=8)
+    w = weights.synth_gpt_weights(cfg, tag="t/gpt/maxlen")
+    w["mel_head.bias"][cfg.stop_mel_token] = -1e4          # never stop: the full 450 steps
+    uv = UnifiedVoice(w, cfg, device=device)
+    tw = {k: torch.from_numpy(v) for k, v in w.items()}
+    B, L, NEW = 2, 600, 450
+    lat = torch.from_numpy(synth.uniform("t/gpt/maxlen/lat", (B, cfg.cond_latents, cfg.model_dim), 0.5))
+    emo = torch.from_numpy(synth.uniform("t/gpt/maxlen/emo", (B, cfg.model_dim), 0.3))
+    text = torch.from_numpy(synth.integers("t/gpt/maxlen/text", (B, L), 2, cfg.number_text_tokens))
+    text[1, 37:] = cfg.stop_text_token                      # a short row next to the maximal one (left-padded prompt)
+    codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, repetition_penalty=10.0)
+    with torch.no_grad():
+        ref = og.generate_greedy(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, NEW, 10.0)
+    assert codes.shape[1] == NEW and np.array_equal(codes.cpu().numpy(), ref.numpy())
