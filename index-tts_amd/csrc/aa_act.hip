@@ -25,7 +25,8 @@
 
 namespace idxtts {
 
-constexpr int AA_TILE = 1024;   // outputs per workgroup (256 threads x 4)
+constexpr int AA_TILE = 1024;   // outputs per tile (256 threads x 4)
+constexpr int AA_TPW = 4;       // consecutive tiles per workgroup (the next tile's loads overlap the current tile's arithmetic)
 constexpr int AA_XH = 8;        // x halo each side (>= 6 needed, 8 keeps float4 alignment)
 constexpr int AA_VH = 4;        // polyphase halo each side (>= 3 needed)
 
@@ -75,7 +76,6 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
   const int c = blockIdx.y, b = blockIdx.z;
   const int Tstride = p.T;                                                     // row stride of the padded tensor
   const int T = RAGGED ? min(p.T, p.lens[b] * p.len_mul) : p.T;               // this row's own length
-  const int t0 = blockIdx.x * AA_TILE;
   const size_t row = ((size_t)b * p.C + c) * Tstride;
   const float* __restrict__ x = p.x + row;
 
@@ -91,18 +91,42 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
   const float a = expf(p.log_alpha[c]);
   const float inv_b = 1.0f / (expf(p.log_beta[c]) + 1e-9f);
 
-  if (RAGGED && t0 >= T) {       // tile entirely in the padding of a shorter row: zeros
+  // A workgroup walks AA_TPW consecutive tiles of its row; the x tile of tile n + 1 is requested (into registers) before tile
+  // n is computed, so the HBM round trip of one tile hides behind the arithmetic of the previous one (a 1024-sample tile is
+  // only 4 KiB in + 4 KiB out: one tile per workgroup left the kernel waiting on memory for 74 % of its wave cycles).
+  constexpr int NXR = (AA_TILE + 2 * AA_XH + 255) / 256;
+  float xr[NXR];
+  auto gload = [&](int t0n) {
+#pragma unroll
+    for (int k = 0; k < NXR; ++k) {
+      const int i = tid + 256 * k;
+      int t = t0n - AA_XH + i;
+      t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+      xr[k] = (i < AA_TILE + 2 * AA_XH && T > 0) ? x[t] : 0.0f;
+    }
+  };
+  const int tile_first = blockIdx.x * AA_TPW;
+  if (!(RAGGED && tile_first * AA_TILE >= T)) gload(tile_first * AA_TILE);
+  for (int tt = 0; tt < AA_TPW; ++tt) {
+  const int t0 = (tile_first + tt) * AA_TILE;
+  if (t0 >= Tstride) break;
+  if (RAGGED && t0 >= T) {       // tile entirely in the padding of a shorter row: zeros (and so are all later tiles)
     float* __restrict__ yz = p.y + row;
     for (int i = tid; i < AA_TILE && t0 + i < Tstride; i += 256) yz[t0 + i] = 0.0f;
-    return;
+    continue;
   }
-  // ---- phase 1: x tile with replicate (clamped) halo ----
-  for (int i = tid; i < AA_TILE + 2 * AA_XH; i += 256) {
-    int t = t0 - AA_XH + i;
-    t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
-    xs[i] = x[t];
+  // ---- phase 1: x tile with replicate (clamped) halo (requested one tile ago) ----
+  __syncthreads();               // the previous tile's phase 3 is done with ve / vo (and phase 2 with xs)
+#pragma unroll
+  for (int k = 0; k < NXR; ++k) {
+    const int i = tid + 256 * k;
+    if (i < AA_TILE + 2 * AA_XH) xs[i] = xr[k];
   }
   __syncthreads();
+  {
+    const int t0n = t0 + AA_TILE;
+    if (tt + 1 < AA_TPW && t0n < Tstride && !(RAGGED && t0n >= T)) gload(t0n);
+  }
 
   // ---- phase 2: polyphase up-sample + SnakeBeta into ve/vo (local index = j - (t0 - AA_VH)) ----
   const int j0 = t0 - AA_VH;
@@ -156,13 +180,13 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
 
   // ---- phase 3: polyphase down-sample, 4 outputs per thread ----
   const int t = t0 + 4 * tid;
-  if (t >= Tstride) return;
+  if (t >= Tstride) continue;    // (no barrier is skipped: the next tile of this row starts beyond Tstride too -> break above)
   if (RAGGED && t >= T) {        // padding of a shorter row inside a partly valid tile
     float* __restrict__ yz = p.y + row;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       if (t + i < Tstride) yz[t + i] = 0.0f;
-    return;
+    continue;                    // the next tile lies wholly in the padding: no barrier there either
   }
   float ew[12], ow[12];
   {
@@ -198,6 +222,7 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
     for (int i = 0; i < 4; ++i)
       if (t + i < Tstride) y[t + i] = t + i < T ? out[i] : 0.0f;
   }
+  }   // tiles of this workgroup
 }
 
 int aa_act_forward(float* y, const float* x, const float* up_f, const float* down_f, const float* log_alpha,
@@ -207,7 +232,7 @@ int aa_act_forward(float* y, const float* x, const float* up_f, const float* dow
   IDX_CHECK(y != x, "aa_act is not in-place safe (tile halos)");
   IDX_CHECK(C <= 65535 && B <= 65535, "grid y/z limit");
   AAParams p{x, y, up_f, down_f, log_alpha, log_beta, C, T, lens, len_mul};
-  dim3 grid(cdiv(T, AA_TILE), C, B);
+  dim3 grid(cdiv(cdiv(T, AA_TILE), AA_TPW), C, B);
   ProfScope prof(PROF_AA_ACT, stream, 0.0, 8.0 * B * C * (double)T);   // one read + one write per element
   if (lens) hipLaunchKernelGGL(aa_act_kernel<true>, grid, dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(aa_act_kernel<false>, grid, dim3(256), 0, stream, p);
