@@ -165,33 +165,43 @@ __global__ __launch_bounds__(256) void rows_norm_kernel(const RowsNormArgs p) {
 // adaLN-RMSNorm of the DiT (d = 512) straight to split-bf16 planes: one 128-lane half-workgroup per row, 16-byte loads,
 // 8-byte plane stores (the four lanes of a 16-k chunk write 32 contiguous bytes; rows of a workgroup are adjacent).
 // Same arithmetic as the generic kernel's NORM_ADA_RMS branch (sum of squares in a different order).
+constexpr int ADA_RPW = 4;      // row pairs per workgroup: the next pair's row is in flight while the current one is normalised
 __global__ __launch_bounds__(256) void ada_rms_planes512_kernel(const RowsNormArgs p) {
-  __shared__ float red[4];
+  __shared__ float red[2][4];
   const int tid = threadIdx.x, half = tid >> 7, t = tid & 127;
-  const int m = blockIdx.x * 2 + half;
-  const bool ok = m < p.M;
-  const f32x4 x = ok ? *reinterpret_cast<const f32x4*>(p.x_in + (size_t)m * p.ld_in + 4 * t) : f32x4{0.f, 0.f, 0.f, 0.f};
-  float ss = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
-  if ((tid & 63) == 0) red[tid >> 6] = ss;
-  __syncthreads();
-  const float r = rsqrtf((red[2 * half] + red[2 * half + 1]) * (1.0f / 512.0f) + p.eps);
-  if (!ok) return;
-  const int b = p.rows_per_batch > 0 ? m / p.rows_per_batch : 0;
   const f32x4 g = *reinterpret_cast<const f32x4*>(p.g1 + 4 * t);
-  f32x4 o = {x[0] * r * g[0], x[1] * r * g[1], x[2] * r * g[2], x[3] * r * g[3]};
-  if (p.mod_a) {
-    const f32x4 wm = *reinterpret_cast<const f32x4*>(p.mod_a + (size_t)b * p.ld_mod + 4 * t);
-    const f32x4 bm = *reinterpret_cast<const f32x4*>(p.mod_b + (size_t)b * p.ld_mod + 4 * t);
-    o = f32x4{wm[0] * o[0] + bm[0], wm[1] * o[1] + bm[1], wm[2] * o[2] + bm[2], wm[3] * o[3] + bm[3]};
-  }
-  idx_bf16x4 hi, lo;
-  split_bf16_x4(o, hi, lo);
   __bf16* y_hi = static_cast<__bf16*>(p.y_planes);
-  const size_t off = plane_index(m, 4 * t, p.M);
-  *reinterpret_cast<idx_bf16x4*>(y_hi + off) = hi;
-  *reinterpret_cast<idx_bf16x4*>(y_hi + plane_elems(p.M, 512) + off) = lo;
+  auto load_row = [&](int m) {
+    return m < p.M ? *reinterpret_cast<const f32x4*>(p.x_in + (size_t)m * p.ld_in + 4 * t) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  const int m0 = blockIdx.x * 2 * ADA_RPW + half;
+  f32x4 xn = load_row(m0);
+#pragma unroll
+  for (int i = 0; i < ADA_RPW; ++i) {
+    const int m = m0 + 2 * i;
+    const f32x4 x = xn;
+    if (i + 1 < ADA_RPW) xn = load_row(m + 2);
+    float ss = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((tid & 63) == 0) red[i & 1][tid >> 6] = ss;
+    __syncthreads();                  // red[] alternates, so one barrier per row pair is enough
+    const float r = rsqrtf((red[i & 1][2 * half] + red[i & 1][2 * half + 1]) * (1.0f / 512.0f) + p.eps);
+    if (m < p.M) {
+      const int b = p.rows_per_batch > 0 ? m / p.rows_per_batch : 0;
+      f32x4 o = {x[0] * r * g[0], x[1] * r * g[1], x[2] * r * g[2], x[3] * r * g[3]};
+      if (p.mod_a) {
+        const f32x4 wm = *reinterpret_cast<const f32x4*>(p.mod_a + (size_t)b * p.ld_mod + 4 * t);
+        const f32x4 bm = *reinterpret_cast<const f32x4*>(p.mod_b + (size_t)b * p.ld_mod + 4 * t);
+        o = f32x4{wm[0] * o[0] + bm[0], wm[1] * o[1] + bm[1], wm[2] * o[2] + bm[2], wm[3] * o[3] + bm[3]};
+      }
+      idx_bf16x4 hi, lo;
+      split_bf16_x4(o, hi, lo);
+      const size_t off = plane_index(m, 4 * t, p.M);
+      *reinterpret_cast<idx_bf16x4*>(y_hi + off) = hi;
+      *reinterpret_cast<idx_bf16x4*>(y_hi + plane_elems(p.M, 512) + off) = lo;
+    }
+  }
 }
 
 int rows_norm_forward(const RowsNormArgs& a, hipStream_t stream) {
@@ -208,7 +218,7 @@ int rows_norm_forward(const RowsNormArgs& a, hipStream_t stream) {
   if (a.mode == NORM_ADA_RMS && a.d == 512 && a.y_planes && !a.y && a.x_in && !a.num_partials && !a.add_bias && !a.x_out && !a.in_frag &&
       a.in_rows_per_batch == 0 && (a.ld_in & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.x_in) | reinterpret_cast<uintptr_t>(a.g1) | reinterpret_cast<uintptr_t>(a.mod_a) |
                                reinterpret_cast<uintptr_t>(a.mod_b)) & 15) == 0 && (a.ld_mod & 3) == 0) {
-    hipLaunchKernelGGL(ada_rms_planes512_kernel, dim3((a.M + 1) / 2), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(ada_rms_planes512_kernel, dim3(cdiv(a.M, 2 * ADA_RPW)), dim3(256), 0, stream, a);
     IDX_LAUNCH_CHECK();
     return 0;
   }
