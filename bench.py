@@ -168,12 +168,61 @@ def build_pipeline(args, world, rank, dev):
     audio_s = B * Tg * cfg.bigvgan.total_upsample / cfg.bigvgan.sampling_rate
     warnings.filterwarnings("ignore", category=RuntimeWarning)
 
-    def step():
+    def step_sequential(last=False):
         c = broadcast_conditioning(cond_dev if rank == 0 else None, shapes, dev) if world > 1 else cond_dev
         wavs = tts.synthesize_batch(text, c, max_mel_tokens=M, noise=noise)
         if world > 1:
             gather_waveforms(wavs, dst=0)
         return wavs[0]
+
+    # Two-stage software pipeline ACROSS steps (default): the decode of batch k + 1 (latency-bound: 125 small launches per
+    # token, MFMA units idle) runs on the main thread's stream while a worker thread runs s2mel + vocoder of batch k
+    # (MFMA-bound) on a second stream; every step's whole work stays inside the timed region (flush() joins the last batch
+    # before the closing barrier), the results are those of the sequential loop, and all collectives stay on the main thread in
+    # a fixed order.  --no-overlap runs the steps strictly one after the other.
+    import concurrent.futures
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+    # The decode's many small launches get the high-priority queue, so they are dispatched ahead of the queued workgroups of
+    # the s2mel GEMMs whenever a CU frees up.  (CU-masked streams, hipExtStreamCreateWithCUMask, are accepted but have no
+    # effect for an unprivileged user on this pool: a masked stream runs an 8192^3 GEMM exactly as fast as a plain one.)
+    lo_pri, hi_pri = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+    s_gpt_full = s_gpt_part = torch.cuda.Stream(device=dev, priority=int(os.environ.get("IDXTTS_DECODE_PRIORITY", hi_pri)))
+    s_ac_full = s_ac_part = torch.cuda.Stream(device=dev, priority=lo_pri)
+    pending = []
+
+    def acoustic_job(st, ev, stream):
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(stream):
+            stream.wait_event(ev)
+            wavs = tts.acoustic_stage(st, noise=noise)
+            stream.synchronize()        # the state's tensors may be released once this returns
+        return wavs
+
+    def retire(fut):
+        wavs = fut.result()
+        if world > 1:
+            gather_waveforms(wavs, dst=0)
+        return wavs[0]
+
+    def step_pipelined(last=False):
+        c = broadcast_conditioning(cond_dev if rank == 0 else None, shapes, dev) if world > 1 else cond_dev
+        sg = s_gpt_part if pending else s_gpt_full
+        sg.wait_stream(torch.cuda.current_stream())         # the broadcast conditioning bundle is produced on the caller's stream
+        with torch.cuda.stream(sg):
+            st = tts.gpt_stage(text, c, max_mel_tokens=M)
+            ev = torch.cuda.Event()
+            ev.record(sg)
+        out = retire(pending.pop(0)) if pending else None
+        pending.append(pool.submit(acoustic_job, st, ev, s_ac_full if last else s_ac_part))
+        return out
+
+    def flush():
+        out = None
+        while pending:
+            out = retire(pending.pop(0))
+        return out
+
+    step = step_sequential if args.no_overlap else step_pipelined
 
     def profiled():
         tts.synthesize_batch(text, cond_dev, max_mel_tokens=M, noise=noise)
@@ -216,6 +265,9 @@ def build_pipeline(args, world, rank, dev):
                         + ("" if not compact else f", GPT linear weights stored as {args.gpt_weights} (rounded once at load; fp32 arithmetic)"),
             "gpt_weights": args.gpt_weights,
             "batch_per_gpu": B, "text_tokens": L, "codes": M, "prompt_frames": Tp, "diffusion_steps": cfg.diffusion_steps}
+    desc["step_overlap"] = ("none" if args.no_overlap else
+                            "two-stage pipeline across steps: decode of batch k+1 overlaps s2mel+vocoder of batch k (two streams, one worker thread)")
+    step.flush = (lambda: None) if args.no_overlap else flush
     return step, profiled, cpu_leg, stage_times, audio_s, desc
 
 
@@ -235,6 +287,9 @@ def main() -> int:
     ap.add_argument("--cpu-codes", type=int, default=96, help="codes of the bounded CPU-baseline utterance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="pipeline workload: run the K steps strictly one after the other (default: the decode of step k+1 overlaps "
+                         "the s2mel + vocoder stages of step k on a second stream)")
     ap.add_argument("--gpt-weights", default=None, choices=["f32", "bf16", "fp8"],
                     help="storage of the GPT linear weights (decode is bound by the weight stream): fp32 (default: the reference's "
                          "own weights, bit for bit), bf16, or fp8-e4m3 with a power-of-two scale per output channel (BASELINE configs[4]); "
@@ -258,11 +313,18 @@ def main() -> int:
         if world == 1 and args.gpus > 1:
             return 2
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the HIP path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs for a one-GPU box (the multi-rank code path end to end, ranks sharing the card over gloo):
+    #   IDXTTS_DIST_BACKEND=gloo IDXTTS_FORCE_DEVICE=0 python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2
+    backend = os.environ.get("IDXTTS_DIST_BACKEND", "nccl")
+    dev_index = int(os.environ.get("IDXTTS_FORCE_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from indextts_amd import _lib
     _lib.load()
@@ -277,14 +339,20 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
+    flush = getattr(step, "flush", lambda: None)
     for i in range(args.warmup):
-        step()
+        step(last=True) if args.workload == "pipeline" else step()
+        flush()
         torch.cuda.synchronize()
         log(f"[bench] rank {rank}: warmup {i + 1}/{args.warmup} done")
     barrier()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    out = None
+    for k in range(args.steps):
+        o = step(last=(k == args.steps - 1)) if args.workload == "pipeline" else step()
+        out = o if o is not None else out
+    o = flush()                     # the last batch's s2mel + vocoder: inside the timed region
+    out = o if o is not None else out
     barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:

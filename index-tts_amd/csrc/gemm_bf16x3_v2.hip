@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 
 #include "gemm_common.h"
 #include "prof.h"
@@ -270,8 +271,9 @@ __global__ __launch_bounds__(256 * WNW) void gemm_bf16x3_v2_kernel(const GemmV2P
 
 // ---- per-stream scratch for the activation planes (grow-only) ----
 struct PlaneScratch { void* ptr = nullptr; size_t bytes = 0; };
-static std::map<hipStream_t, PlaneScratch> g_scratch;
-static const __bf16* g_zero_page = nullptr;
+static std::map<hipStream_t, PlaneScratch> g_scratch;      // guarded by g_scratch_mu: stages of different batches may run on
+static const __bf16* g_zero_page = nullptr;                 // different host threads / streams (bench.py's two-stage pipeline)
+static std::mutex g_scratch_mu;
 
 bool gemm_bf16x3_v2_enabled() {
   static const bool on = !(getenv("IDXTTS_GEMM_V2") && atoi(getenv("IDXTTS_GEMM_V2")) == 0);
@@ -284,7 +286,8 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
   IDX_CHECK(w.K % 16 == 0 && (a.taps <= 1 || (w.K / a.taps) % 16 == 0), "v2 needs K % 16 == 0");
   const int xk = a.taps > 1 ? w.K / a.taps : w.K;       // channels of the activation rows
   const size_t plane = (size_t)(xk / 16) * a.M * 16 * sizeof(__bf16);
-  PlaneScratch& sc = g_scratch[stream];
+  std::unique_lock<std::mutex> lock(g_scratch_mu);
+  PlaneScratch& sc = g_scratch[stream];      // (map nodes are stable: the reference outlives the lock; a stream has one user)
   if (!a.x_planes && sc.bytes < 2 * plane) {
     IDX_HIP(hipStreamSynchronize(stream));
     if (sc.ptr) IDX_HIP(hipFree(sc.ptr));
@@ -297,6 +300,7 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
     IDX_HIP(hipMemset(z, 0, 4096));
     g_zero_page = static_cast<const __bf16*>(z);
   }
+  lock.unlock();
   const __bf16* hi = a.x_planes ? static_cast<const __bf16*>(a.x_planes) : static_cast<const __bf16*>(sc.ptr);
   const __bf16* lo = hi + plane / sizeof(__bf16);
   if (!a.x_planes) {

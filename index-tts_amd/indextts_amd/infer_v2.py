@@ -132,24 +132,34 @@ class IndexTTS2:
         sampling: None = greedy; else the num_beams=1 sampling kwargs of UnifiedVoice.inference_speech
         (do_sample, temperature, top_k, top_p, sampler, exp_noise / generator).
         per_row_noise: draw the CFM noise row by row, `randn([1, 80, Tp + Tg_b])` in row order -- the draws the reference's
-        sequential segment loop makes (flow_matching.py:62 once per segment) -- instead of one [B, 80, T] draw."""
+        sequential segment loop makes (flow_matching.py:62 once per segment) -- instead of one [B, 80, T] draw.
+        = acoustic_stage(gpt_stage(...)): the two halves are separate entry points so that a serving loop can overlap the
+        (latency-bound) decode of one batch with the (MFMA-bound) s2mel + vocoder of the previous one on another stream."""
+        st = self.gpt_stage(text_tokens, cond, max_mel_tokens=max_mel_tokens, repetition_penalty=repetition_penalty,
+                            sampling=sampling, sync_timers=sync_timers)
+        return self.acoustic_stage(st, noise=noise, per_row_noise=per_row_noise, sync_timers=sync_timers,
+                                   return_intermediates=return_intermediates)
+
+    def _tick(self, sync: bool) -> float:
+        if sync:
+            torch.cuda.synchronize(self.device)
+        return time.perf_counter()
+
+    def gpt_stage(self, text_tokens: torch.Tensor, cond: PromptConditioning, max_mel_tokens: int = 1500,
+                  repetition_penalty: float = 10.0, sampling: Optional[dict] = None, sync_timers: bool = False) -> dict:
+        """Decode + stop-token trim + latent pass (infer_v2.py:732-828) on the current stream; returns the state
+        acoustic_stage consumes (device tensors + host lengths)."""
         dev = self.device
         c = cond.to(dev)
         B = text_tokens.shape[0]
         times = {}
-
-        def tick():
-            if sync_timers:
-                torch.cuda.synchronize(dev)
-            return time.perf_counter()
-
-        t0 = tick()
+        t0 = self._tick(sync_timers)
         lat = c.spk_cond_latent.expand(B, -1, -1) if c.spk_cond_latent.shape[0] == 1 else c.spk_cond_latent
         emo = c.emo_vec.expand(B, -1) if c.emo_vec.shape[0] == 1 else c.emo_vec
         codes, _ = self.gpt.inference_speech(lat, text_tokens, emo_vec=emo, max_generate_length=max_mel_tokens,
                                              repetition_penalty=repetition_penalty, num_beams=1,
                                              **(sampling if sampling else {"do_sample": False}))
-        t1 = tick()
+        t1 = self._tick(sync_timers)
         times["gpt_gen_time"] = t1 - t0
         # trim at the first stop token (infer_v2.py:795-807)
         hc = codes.cpu().numpy()
@@ -168,8 +178,17 @@ class IndexTTS2:
         tt = torch.as_tensor(text_tokens).cpu()
         text_lens = ((tt != self.cfg.gpt.stop_text_token) & (tt != self.cfg.gpt.start_text_token)).sum(1)
         latent = self.gpt.forward(lat, text_tokens, text_lens, codes, code_lens_t, emo_vec=emo)
-        t2 = tick()
+        t2 = self._tick(sync_timers)
         times["gpt_forward_time"] = t2 - t1
+        return {"cond": c, "B": B, "codes": codes, "code_lens": code_lens, "code_lens_t": code_lens_t, "latent": latent, "times": times}
+
+    def acoustic_stage(self, st: dict, noise: Optional[torch.Tensor] = None, per_row_noise: bool = False, sync_timers: bool = False,
+                       return_intermediates: bool = False):
+        """s2mel (length regulator + CFM) and the vocoder (infer_v2.py:835-866) on the current stream."""
+        dev = self.device
+        c, B, codes, code_lens, code_lens_t, latent, times = (st["cond"], st["B"], st["codes"], st["code_lens"], st["code_lens_t"],
+                                                              st["latent"], dict(st["times"]))
+        t2 = self._tick(sync_timers)
         condv, target_lens = self.s2mel.prepare_condition(latent, codes, code_lens_t)
         Tp = c.prompt_condition.shape[1]
         Tg = condv.shape[1]
@@ -185,7 +204,7 @@ class IndexTTS2:
         mel = self.s2mel.cfm_inference(cat_condition, x_lens, c.ref_mel.expand(B, -1, -1), c.style.expand(B, -1), None,
                                        self._diffusion_steps, inference_cfg_rate=self._cfg_rate, z=noise)
         vc_target = mel[:, :, Tp:]                                                          # infer_v2.py:856
-        t3 = tick()
+        t3 = self._tick(sync_timers)
         times["s2mel_time"] = t3 - t2
         # vocoder: one ragged batch; every layer pads at each row's OWN end (zeros for the convolutions, replicate for the
         # anti-alias filters), exactly what the reference's B=1 call per utterance sees (infer_v2.py:860)
@@ -197,7 +216,7 @@ class IndexTTS2:
         up = self.cfg.bigvgan.total_upsample
         for b in range(B):
             wavs[b] = w[b, :, : tl[b] * up].contiguous()
-        t4 = tick()
+        t4 = self._tick(sync_timers)
         times["bigvgan_time"] = t4 - t3
         self.last_stage_times = times
         if return_intermediates:
