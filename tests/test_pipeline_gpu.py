@@ -121,3 +121,40 @@ def test_infer_streaming_contract(device):
     _, two = tts.infer(cond, seg, None, max_mel_tokens=16, interval_silence=100)
     assert two.shape == whole.shape and np.abs(two.astype(np.int32) - whole.astype(np.int32)).max() <= 3
     assert list(tts.infer(cond, [], None, stream_return=True)) == []
+
+
+def test_stages_overlapped_on_two_streams_equal_the_sequential_flow(device):
+    """gpt_stage / acoustic_stage are what bench.py's two-stage pipeline runs on two streams and two host threads: the decode
+    of batch k + 1 beside the s2mel + vocoder of batch k must give bit for bit the waveforms of the sequential calls."""
+    import concurrent.futures
+    cfg, wg, ws, wv, tts, cond = _build(device, eos_bias=6.5)
+    dev = torch.device(device)
+    texts = [torch.from_numpy(synth.integers(f"t/pipe/ovl/{i}", (3, 7), 2, cfg.gpt.number_text_tokens)) for i in range(3)]
+
+    def acoustic(st, seed):
+        torch.manual_seed(seed)                 # the CFM noise is the only random draw (greedy decode)
+        return [w.cpu() for w in tts.acoustic_stage(st)]
+    want = [acoustic(tts.gpt_stage(t, cond, max_mel_tokens=14), 100 + i) for i, t in enumerate(texts)]
+
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+
+    def job(st, ev, seed):
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(s2):
+            s2.wait_event(ev)
+            out = acoustic(st, seed)
+            s2.synchronize()
+        return out
+    futs = []
+    for i, t in enumerate(texts):
+        with torch.cuda.stream(s1):
+            st = tts.gpt_stage(t, cond, max_mel_tokens=14)
+            ev = torch.cuda.Event()
+            ev.record(s1)
+        futs.append(pool.submit(job, st, ev, 100 + i))      # runs beside the next batch's gpt_stage
+    got = [f.result() for f in futs]
+    for w_seq, w_ovl in zip(want, got):
+        assert len(w_seq) == len(w_ovl)
+        for a, b in zip(w_seq, w_ovl):
+            assert a.shape == b.shape and torch.equal(a, b)
