@@ -55,7 +55,8 @@ struct GPTModel : ModelBase {
   int head_and_sample(const Buffers& w, int B, const float* x, int ldx, bool x_frag, float penalty, long long* codes, int codes_ld,
                       float* logits_out, hipStream_t st);
   int decode_step(const Buffers& w, int B, float penalty, long long* codes, int codes_ld, float* logits_base, hipStream_t st);
-  idxtts_sampling samp{0, 1.0f, 0, 1.0f, nullptr};     // sampling mode of the generation in flight (mode 0 = greedy)
+  // (the sampling mode of the generation in flight is thread-local state in gpt.hip: generate() is re-entrant across host threads,
+  //  each call with its own workspace and stream)
   int generate(const float* inputs_embeds, const int* pad_left_host, int B, int P, int max_new, float penalty, const idxtts_sampling* sampling, long long* codes,
                int* n_steps_out, float* logits_out, void* ws, size_t ws_bytes, int use_graph, hipStream_t st);
   int latent(const float* emb, const int* pad_left_host, int B, int S, int mel_start, int M, float* latent_out, void* ws, size_t ws_bytes,

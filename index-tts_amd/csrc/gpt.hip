@@ -289,6 +289,9 @@ int GPTModel::layer_full(int li, const Buffers& w, int B, int S, const int* ksta
   return 0;
 }
 
+// sampling mode of the generation this host thread is running (mode 0 = greedy)
+static thread_local idxtts_sampling samp{0, 1.0f, 0, 1.0f, nullptr};
+
 // head on B rows: ln_f -> final_norm (one rows_norm launch, output as fragment images) -> mel_head -> greedy sampler
 int GPTModel::head_and_sample(const Buffers& w, int B, const float* x, int ldx, bool x_frag, float penalty, long long* codes,
                               int codes_ld, float* logits_out, hipStream_t st) {

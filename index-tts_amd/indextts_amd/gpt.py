@@ -78,10 +78,15 @@ class UnifiedVoice:
         need = int(_lib.load().idxtts_gpt_workspace_bytes(self._h, B, S, max_new))
         if need == 0:
             raise RuntimeError("idxtts_gpt_workspace_bytes returned 0")
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        import threading
+        if self._ws is None:
+            self._ws = {}
+        key = threading.get_ident()                  # one workspace per host thread: generate() may run concurrently on several streams
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            self._ws.pop(key, None)
+            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws
 
     def _embed(self, rows: int, text_ids=None, text_pos=None, mel_ids=None, mel_pos=None, extra=None, extra_idx=None):
         out = torch.empty(rows, self.cfg.model_dim, device=self.device, dtype=torch.float32)
