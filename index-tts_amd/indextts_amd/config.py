@@ -46,6 +46,26 @@ class BigVGANConfig:
 
 
 @dataclass(frozen=True)
+class CondModuleConfig:
+    """Conformer + perceiver prompt encoder (config.yaml:29-43 `condition_module` / `emo_condition_module`;
+    conformer_encoder.py:436-520, perceiver.py:193-245).  The conformer input is always 1024 wide (w2v-bert features,
+    model_v2.py:396, 406) through `Conv2dSubsampling2` (subsampling.py:131-181)."""
+    output_size: int = 512
+    linear_units: int = 2048
+    attention_heads: int = 8
+    num_blocks: int = 6
+    perceiver_mult: int = 2
+    cnn_kernel: int = 15             # ConformerEncoder default cnn_module_kernel
+    input_size: int = 1024
+    perceiver_depth: int = 2         # PerceiverResampler default
+    perceiver_dim_head: int = 64
+
+    @property
+    def sub_freq(self) -> int:       # features left by the 3x3 stride-2 conv: (idim - 1) // 2
+        return (self.input_size - 1) // 2
+
+
+@dataclass(frozen=True)
 class GPTConfig:
     model_dim: int = 1280
     heads: int = 20
@@ -59,6 +79,9 @@ class GPTConfig:
     max_mel_tokens: int = 1815
     max_text_tokens: int = 600
     cond_latents: int = 32            # perceiver latents; +2 speed embeddings = 34 prefix rows
+    cond_module: CondModuleConfig = field(default_factory=CondModuleConfig)
+    emo_cond_module: CondModuleConfig = field(default_factory=lambda: CondModuleConfig(linear_units=1024, attention_heads=4, num_blocks=4))
+    emo_perceiver_dim: int = 1024     # hard-coded in the reference (model_v2.py:412, 420)
 
     @property
     def head_dim(self) -> int:
@@ -80,7 +103,9 @@ class GPTConfig:
     def tiny() -> "GPTConfig":
         return GPTConfig(model_dim=128, heads=2, layers=3, number_text_tokens=300,
                          number_mel_codes=258, start_mel_token=256, stop_mel_token=257,
-                         max_mel_tokens=120, max_text_tokens=60, cond_latents=6)
+                         max_mel_tokens=120, max_text_tokens=60, cond_latents=6,
+                         cond_module=CondModuleConfig(output_size=32, linear_units=64, attention_heads=2, num_blocks=2),
+                         emo_cond_module=CondModuleConfig(output_size=32, linear_units=48, attention_heads=2, num_blocks=1))
 
 
 @dataclass(frozen=True)

@@ -104,6 +104,74 @@ def synth_gpt_weights(cfg: GPTConfig, tag: str = "gpt") -> Weights:
     return w
 
 
+def synth_gpt_cond_weights(cfg: GPTConfig, tag: str = "gpt") -> Weights:
+    """Keys/shapes of the prompt-conditioning half of `UnifiedVoice.state_dict()` (model_v2.py:396-423):
+    `conditioning_encoder.*` / `emo_conditioning_encoder.*` (ConformerEncoder, conformer_encoder.py:436-520),
+    `perceiver_encoder.*` / `emo_perceiver_encoder.*` (PerceiverResampler, perceiver.py:193-245), `emovec_layer`, `emo_layer`.
+    The sinusoid buffer `embed.pos_enc.pe` is not a weight: consumers rebuild it (embedding.py:45-53)."""
+    w: Weights = {}
+    d = cfg.model_dim
+
+    def u(name, shape, scale, offset=0.0):
+        w[name] = synth.uniform(f"{tag}/{name}", shape, scale, offset)
+
+    def lin(name, n_out, n_in, gain=1.0, bias=True, bscale=0.05):
+        w[f"{name}.weight"] = synth.fan_in_uniform(f"{tag}/{name}.weight", (n_out, n_in), n_in, gain)
+        if bias:
+            u(f"{name}.bias", (n_out,), bscale)
+
+    def ln(name, n):
+        u(f"{name}.weight", (n,), 0.2, 1.0)
+        u(f"{name}.bias", (n,), 0.1)
+
+    def conformer(p, m):
+        D, hd = m.output_size, m.output_size // m.attention_heads
+        w[f"{p}.embed.conv.0.weight"] = synth.fan_in_uniform(f"{tag}/{p}.embed.conv.0.weight", (D, 1, 3, 3), 9, 1.5)
+        u(f"{p}.embed.conv.0.bias", (D,), 0.3)
+        lin(f"{p}.embed.out.0", D, D * m.sub_freq, 1.6)
+        ln(f"{p}.after_norm", D)
+        for i in range(m.num_blocks):
+            e = f"{p}.encoders.{i}"
+            u(f"{e}.self_attn.pos_bias_u", (m.attention_heads, hd), 0.3)
+            u(f"{e}.self_attn.pos_bias_v", (m.attention_heads, hd), 0.3)
+            for nm in ("linear_q", "linear_k", "linear_v"):
+                lin(f"{e}.self_attn.{nm}", D, D, 1.2)
+            lin(f"{e}.self_attn.linear_out", D, D, 0.7)
+            lin(f"{e}.self_attn.linear_pos", D, D, 1.0, bias=False)
+            lin(f"{e}.feed_forward.w_1", m.linear_units, D, 1.0)
+            lin(f"{e}.feed_forward.w_2", D, m.linear_units, 0.7)
+            w[f"{e}.conv_module.pointwise_conv1.weight"] = synth.fan_in_uniform(f"{tag}/{e}.conv_module.pointwise_conv1.weight", (2 * D, D, 1), D, 1.2)
+            u(f"{e}.conv_module.pointwise_conv1.bias", (2 * D,), 0.05)
+            w[f"{e}.conv_module.depthwise_conv.weight"] = synth.fan_in_uniform(f"{tag}/{e}.conv_module.depthwise_conv.weight", (D, 1, m.cnn_kernel), m.cnn_kernel, 1.5)
+            u(f"{e}.conv_module.depthwise_conv.bias", (D,), 0.05)
+            ln(f"{e}.conv_module.norm", D)
+            w[f"{e}.conv_module.pointwise_conv2.weight"] = synth.fan_in_uniform(f"{tag}/{e}.conv_module.pointwise_conv2.weight", (D, D, 1), D, 0.8)
+            u(f"{e}.conv_module.pointwise_conv2.bias", (D,), 0.05)
+            for nm in ("norm_ff", "norm_mha", "norm_conv", "norm_final"):
+                ln(f"{e}.{nm}", D)
+
+    def perceiver(p, dim, m, n_latents):
+        inner = m.perceiver_dim_head * m.attention_heads
+        ff = int(dim * m.perceiver_mult * 2 / 3)             # perceiver.py:181
+        u(f"{p}.latents", (n_latents, dim), 0.5)
+        lin(f"{p}.proj_context", dim, m.output_size, 1.0)
+        for l in range(m.perceiver_depth):
+            lin(f"{p}.layers.{l}.0.to_q", inner, dim, 1.2, bias=False)
+            lin(f"{p}.layers.{l}.0.to_kv", 2 * inner, dim, 1.2, bias=False)
+            lin(f"{p}.layers.{l}.0.to_out", dim, inner, 0.7, bias=False)
+            lin(f"{p}.layers.{l}.1.0", 2 * ff, dim, 1.0)
+            lin(f"{p}.layers.{l}.1.2", dim, ff, 0.7)
+        u(f"{p}.norm.gamma", (dim,), 0.2, 1.0)
+
+    conformer("conditioning_encoder", cfg.cond_module)
+    perceiver("perceiver_encoder", d, cfg.cond_module, cfg.cond_latents)
+    conformer("emo_conditioning_encoder", cfg.emo_cond_module)
+    perceiver("emo_perceiver_encoder", cfg.emo_perceiver_dim, cfg.emo_cond_module, 1)
+    lin("emovec_layer", d, cfg.emo_perceiver_dim, 1.0)
+    lin("emo_layer", d, d, 1.0)
+    return w
+
+
 # --------------------------------------------------------------------------------------
 # s2mel (MyModel: cfm / length_regulator / gpt_layer, commons.py:390-420) + the semantic-codec
 # vq2emb tables (residual_vq.py:144-152, factorized_vector_quantize.py:123-127)

@@ -351,6 +351,185 @@ def make_gpt():
     print("wrote gpt.npz", {k: v.shape for k, v in out.items()}, "codes", out["greedy_codes"].tolist())
 
 
+def _import_reference_model_v2():
+    """`import indextts.gpt.model_v2` from /root/reference.  Its module-level imports name three things this image lacks:
+    the vendored `indextts.gpt.transformers_gpt2` (its sibling `transformers_generation_utils.py:28` needs
+    `transformers.cache_utils.OffloadedCache`, gone in transformers 5.x), `transformers.utils.model_parallel_utils` (dead
+    `parallelize()` code) and `torchaudio` (pulled in by `indextts.utils.common` for an unrelated loader).  The first is
+    satisfied by re-exporting the container's `GPT2PreTrainedModel` / `GPT2Model` -- the very classes `model_v2.py:290`
+    instantiates from upstream `transformers` anyway -- the other two by inert placeholders."""
+    import contextlib
+    import importlib.machinery
+    import io
+    import transformers
+    from transformers import GPT2Model, GPT2PreTrainedModel
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        sys.modules[name] = m
+
+    # model_v2.py:149-151, 194-198 converts the KV cache through `DynamicCache.{from,to}_legacy_cache`, two pure container
+    # conversions of transformers 4.52.1 (cache_utils.py there: tuple of per-layer (key, value) <-> DynamicCache.update per
+    # layer) that 5.x dropped.  Restored here, in the fixture generator's process only, so the reference's forward runs unmodified.
+    from transformers.cache_utils import DynamicCache
+    if not hasattr(DynamicCache, "to_legacy_cache"):
+        def to_legacy_cache(self):
+            return tuple((l.keys, l.values) for l in self.layers)
+
+        def from_legacy_cache(cls, past_key_values=None):
+            c = cls()
+            for i, (k, v) in enumerate(past_key_values or ()):
+                c.update(k, v, i)
+            return c
+        DynamicCache.to_legacy_cache = to_legacy_cache
+        DynamicCache.from_legacy_cache = classmethod(from_legacy_cache)
+    stub("indextts.gpt.transformers_gpt2", GPT2PreTrainedModel=GPT2PreTrainedModel, GPT2Model=GPT2Model)
+    stub("transformers.utils.model_parallel_utils", assert_device_map=None, get_device_map=None)
+    stub("torchaudio")
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    with contextlib.redirect_stdout(io.StringIO()):
+        import indextts.gpt.model_v2 as mv
+    return mv
+
+
+def build_reference_unified_voice(mv, cfg, w):
+    """The reference's own `UnifiedVoice` (model_v2.py:338-560) at `cfg`'s sizes carrying the synthetic weights `w`."""
+    import contextlib
+    import io
+    cm, em = cfg.cond_module, cfg.emo_cond_module
+    as_dict = lambda m: dict(output_size=m.output_size, linear_units=m.linear_units, attention_heads=m.attention_heads,
+                             num_blocks=m.num_blocks, input_layer="conv2d2", perceiver_mult=m.perceiver_mult)
+    uv = mv.UnifiedVoice(layers=cfg.layers, model_dim=cfg.model_dim, heads=cfg.heads, max_text_tokens=cfg.max_text_tokens,
+                         max_mel_tokens=cfg.max_mel_tokens, number_text_tokens=cfg.number_text_tokens,
+                         number_mel_codes=cfg.number_mel_codes, start_mel_token=cfg.start_mel_token,
+                         stop_mel_token=cfg.stop_mel_token, start_text_token=cfg.start_text_token,
+                         stop_text_token=cfg.stop_text_token, condition_num_latent=cfg.cond_latents,
+                         condition_type="conformer_perceiver", condition_module=as_dict(cm), emo_condition_module=as_dict(em))
+    missing, unexpected = uv.load_state_dict(_sd(w), strict=False)
+    assert not unexpected, unexpected
+    for k in missing:   # buffers and the unused text head only
+        assert k.endswith("pos_enc.pe") or k.startswith("text_head.") or k.endswith("attn.bias") or k.endswith("masked_bias"), k
+    with contextlib.redirect_stdout(io.StringIO()):
+        uv.post_init_gpt2_config(use_deepspeed=False, kv_cache=True, half=False)
+    return uv.eval()
+
+
+def make_gpt_ref():
+    """GPT fixtures produced by the REFERENCE's own `UnifiedVoice` / `GPT2InferenceModel` code (model_v2.py), imported from
+    /root/reference: conditioning encoders, emotion vector, prompt layout, cached decode forward, latent pass and -- through
+    the container's HF `generate` driving the reference's `prepare_inputs_for_generation` / `forward` -- greedy and
+    beam-sample token sequences."""
+    import contextlib
+    import io
+    from indextts_amd import synth, weights
+    from indextts_amd.config import GPTConfig
+    mv = _import_reference_model_v2()
+    cfg = GPTConfig.tiny()
+    d = cfg.model_dim
+    w = weights.synth_gpt_weights(cfg, tag="golden/gptref")
+    w.update(weights.synth_gpt_cond_weights(cfg, tag="golden/gptref"))
+    uv = build_reference_unified_voice(mv, cfg, w)
+    out = {}
+    quiet = lambda: contextlib.redirect_stdout(io.StringIO())
+
+    # ---- a8: conditioning (model_v2.py:627-671, 897-910).  One prompt as infer_v2.py:748-765 passes it ([1,T,1024], the
+    #      "length" is shape[-1] = 1024, i.e. no padding), plus a ragged pair with true lengths for the mask path ----
+    spk = torch.from_numpy(synth.uniform("golden/gptref/spk", (1, 23, 1024), 1.0))
+    emo = torch.from_numpy(synth.uniform("golden/gptref/emo", (1, 19, 1024), 1.0))
+    with torch.no_grad():
+        ln_spk = torch.tensor([spk.shape[-1]])
+        ln_emo = torch.tensor([emo.shape[-1]])
+        lat = uv.get_conditioning(spk.transpose(1, 2), ln_spk)                 # [1, 6, d]
+        out["cond_latent"] = lat.numpy()
+        out["emovec_spk"] = uv.get_emovec(spk, ln_spk).numpy()
+        out["emovec_emo"] = uv.get_emovec(emo, ln_emo).numpy()
+        out["emovec_merged"] = uv.merge_emovec(spk, emo, ln_spk, ln_emo, alpha=0.6).numpy()
+        enc, mask = uv.conditioning_encoder(spk, ln_spk)
+        out["conformer_out"] = enc.numpy()
+        pair = torch.from_numpy(synth.uniform("golden/gptref/pair", (2, 21, 1024), 1.0))
+        plen = torch.tensor([21, 14])
+        pair[1, 14:] = 0.0
+        out["cond_latent_ragged"] = uv.get_conditioning(pair.transpose(1, 2), plen).numpy()
+        out["emovec_ragged"] = uv.get_emovec(pair, plen).numpy()
+    emovec = torch.from_numpy(out["emovec_merged"])
+
+    # ---- a2: prompt layout, the reference's own prepare_gpt_inputs on ragged rows (model_v2.py:725-794) ----
+    B, L, NEW = 3, 12, 10
+    text = torch.from_numpy(synth.integers("golden/gptref/text", (B, L), 2, cfg.number_text_tokens))
+    text[1, 9:] = cfg.stop_text_token
+    text[2, 5:] = cfg.stop_text_token
+    with torch.no_grad():
+        zero = torch.zeros(B).long()
+        conds = torch.cat((lat.expand(B, -1, -1) + emovec.expand(B, -1).unsqueeze(1),
+                           uv.speed_emb(torch.ones_like(zero)).unsqueeze(1), uv.speed_emb(zero).unsqueeze(1)), 1)   # model_v2.py:830-834
+        fake, inputs_embeds, attention_mask = uv.prepare_gpt_inputs(conds, text)
+    out["text"] = text.numpy()
+    out["conds"] = conds.numpy()
+    out["prep_fake"] = fake.numpy()
+    out["prep_embeds"] = inputs_embeds.numpy()
+    out["prep_mask"] = attention_mask.numpy()
+
+    # ---- a3: GPT2InferenceModel.forward (model_v2.py:131-225) driven the way generate drives it: prefill, then cached
+    #      single-token steps through its own prepare_inputs_for_generation (101-129); greedy choice by hand (argmax of
+    #      the HF repetition-penalty processor) so every step's logits are recorded ----
+    from transformers.generation.logits_process import RepetitionPenaltyLogitsProcessor
+    proc = RepetitionPenaltyLogitsProcessor(penalty=10.0)
+    im = uv.inference_model
+    im.store_mel_emb(inputs_embeds)
+    ids, mask, past = fake.clone(), attention_mask.clone(), None
+    logits_all = []
+    unfinished = torch.ones(B, dtype=torch.long)
+    with torch.no_grad():
+        for step in range(NEW):
+            mi = im.prepare_inputs_for_generation(ids, past_key_values=past, attention_mask=mask, use_cache=True)
+            o = im(**mi, return_dict=True)
+            past = o.past_key_values
+            logits = o.logits[:, -1].float()
+            logits_all.append(logits.clone())
+            nxt = torch.argmax(proc(ids, logits.clone()), -1)
+            nxt = nxt * unfinished + cfg.stop_mel_token * (1 - unfinished)
+            ids = torch.cat([ids, nxt[:, None]], 1)
+            mask = torch.cat([mask, torch.ones(B, 1, dtype=torch.long)], 1)
+            unfinished = unfinished & (nxt != cfg.stop_mel_token).long()
+    out["step_logits"] = torch.stack(logits_all, 1).numpy()
+    out["step_codes"] = ids[:, fake.shape[1]:].numpy()
+
+    # ---- a5/a6: the reference's inference_speech (model_v2.py:796-895) end to end: greedy, HF generate of this image ----
+    def speech(**kw):
+        with torch.no_grad(), quiet():
+            codes, lat_ = uv.inference_speech(spk, text, emo, cond_lengths=ln_spk, emo_cond_lengths=ln_emo, emo_vec=emovec.expand(B, -1),
+                                              num_return_sequences=1, max_generate_length=NEW, **kw)
+        return codes, lat_
+    try:
+        # transformers 5.x `generate` pre-populates its default cache with one (empty) layer object per block, which is truthy;
+        # the reference's `if past_key_values:` (model_v2.py:106), written against 4.52.1's empty-and-falsy DynamicCache(),
+        # would then treat the prefill as a cached step.  Handing generate an empty DynamicCache() restores the 4.52.1 flow.
+        from transformers.cache_utils import DynamicCache
+        codes, lat_ = speech(do_sample=False, num_beams=1, repetition_penalty=10.0, past_key_values=DynamicCache())
+        out["speech_greedy_codes"] = codes.numpy()
+        out["speech_latent"] = lat_.numpy()
+        print("inference_speech greedy:", codes.tolist())
+    except Exception as e:      # recorded, not hidden: DESIGN section 2 quotes this line
+        print("inference_speech(greedy) through container HF generate failed:", type(e).__name__, e)
+
+    # ---- a7: latent pass, the reference's UnifiedVoice.forward (model_v2.py:673-723) ----
+    B2, L2, M2 = 2, 7, 9
+    text2 = torch.from_numpy(synth.integers("golden/gptref/text2", (B2, L2), 2, cfg.number_text_tokens))
+    codes2 = torch.from_numpy(synth.integers("golden/gptref/codes2", (B2, M2), 0, cfg.start_mel_token))
+    with torch.no_grad():
+        latent = uv(lat.expand(B2, -1, -1), text2.clone(), torch.tensor([L2, L2]), codes2.clone(), torch.tensor([M2, M2]), emo,
+                    cond_mel_lengths=ln_spk, emo_cond_mel_lengths=ln_emo, emo_vec=emovec.expand(B2, -1), use_speed=torch.zeros(B2).long())
+    out["latent_text"] = text2.numpy()
+    out["latent_codes"] = codes2.numpy()
+    out["latent"] = latent.numpy()
+    np.savez_compressed(os.path.join(HERE, "gpt_ref.npz"), **out)
+    print("wrote gpt_ref.npz", {k: v.shape for k, v in out.items()})
+    return uv, cfg, w, out
+
+
 def make_segments():
     """Segment-splitter fixtures from the reference's TextTokenizer.split_segments_by_token (front.py:345-422): random token
     streams over a small SentencePiece-like vocabulary (words, commas, dashes, apostrophes, sentence punctuation)."""
@@ -381,6 +560,8 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     if which in ("gpt", "all"):          # before the placeholders: transformers probes for torchaudio
         make_gpt()
+    if which in ("gpt_ref", "all"):
+        make_gpt_ref()
     if which in ("vocoder", "s2mel", "all"):
         Munch = _install_placeholders()
         if which in ("vocoder", "all"):
