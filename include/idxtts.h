@@ -195,6 +195,30 @@ int idxtts_gpt_generate_sampled(idxtts_ctx* ctx, const float* inputs_embeds, con
 int idxtts_gpt_latent(idxtts_ctx* ctx, const float* emb, const int* pad_left, int B, int S, int mel_start, int M, float* latent,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- prompt-conditioning encoders (reference: UnifiedVoice.get_conditioning model_v2.py:627-663, get_emo_conditioning
+ * 665-671, get_emovec / merge_emovec 897-910; ConformerEncoder conformer_encoder.py:284-520; PerceiverResampler
+ * perceiver.py:193-317).  One context per encoder pair:
+ *   emotion = 0: keys "conditioning_encoder.*" + "perceiver_encoder.*"            -> latents [B][num_latents][perceiver_dim]
+ *   emotion = 1: keys "emo_conditioning_encoder.*" + "emo_perceiver_encoder.*" + "emovec_layer.*" + "emo_layer.*"
+ *                                                                                 -> emotion vector [B][model_dim] (get_emovec)
+ * The sinusoid buffer "<encoder>.embed.pos_enc.pe" [1][max_len][output_size] of the reference's state_dict is a required
+ * tensor (embedding.py:45-53). */
+typedef struct idxtts_cond_config {
+  int input_size;                                   /* 1024 (w2v-bert features) */
+  int output_size, linear_units, attention_heads, num_blocks, cnn_kernel;   /* 512, 2048 | 1024, 8 | 4, 6 | 4, 15 */
+  int perceiver_dim, num_latents, perceiver_depth, perceiver_dim_head, perceiver_mult;   /* 1280 | 1024, 32 | 1, 2, 64, 2 */
+  int emotion;
+  int model_dim;                                    /* 1280: width of emovec_layer / emo_layer (emotion = 1) */
+} idxtts_cond_config;
+int idxtts_cond_create(const idxtts_cond_config* cfg, idxtts_ctx** out);
+size_t idxtts_cond_workspace_bytes(const idxtts_ctx* ctx, int B, int T);
+/* feats: device [B][T][input_size]; lengths: HOST int32 [B] valid frames per prompt, or NULL = all T (values > T are
+ * clamped: the reference passes the feature width 1024 as "length", infer_v2.py:751-752, i.e. no padding). */
+int idxtts_cond_forward(idxtts_ctx* ctx, const float* feats, const int* lengths, int B, int T, float* out, void* workspace,
+                        size_t workspace_bytes, void* stream);
+/* out = base + alpha * (emo - base) over n floats (merge_emovec, model_v2.py:904-910). */
+int idxtts_emovec_merge(float* out, const float* base, const float* emo, float alpha, size_t n, void* stream);
+
 /* ---- s2mel stage (reference: infer_v2.py:835-856; MyModel commons.py:390-420) -------------------------
  * State-dict keys: "cfm.estimator.*", "length_regulator.*", "gpt_layer.{0,1,2}.*" (s2mel.pth['net'][...], weight-norm
  * layers folded to plain ".weight"), "semantic_codec.quantizer.quantizers.0.{codebook.weight,out_project.weight,out_project.bias}",
@@ -224,6 +248,15 @@ size_t idxtts_s2mel_cfm_workspace_bytes(const idxtts_ctx* ctx, int B, int T, int
 int idxtts_s2mel_cfm(idxtts_ctx* ctx, const float* mu, const int* x_lens, const float* prompt, const int* prompt_lens, int Tp_max,
                      const float* style, const float* z, const float* t_emb, const float* dt, int n_steps, float cfg_rate,
                      float* out, int B, int T, void* workspace, size_t workspace_bytes, void* stream);
+
+/* One evaluation of the CFM estimator = DiT.forward(x, prompt_x, x_lens, t, style, cond) (diffusion_transformer.py:186-257),
+ * the function `cfm.inference` calls once per Euler step on the [cond | null] stack (flow_matching.py:96).  x [B][in_channels][T];
+ * prompt [B][in_channels][Tp_max] with prompt_lens HOST [B] (prompt_x is zero beyond them); x_lens HOST [B]; t_emb device
+ * [1][256] sinusoidal features of the (shared) timestep; style [B][style_dim]; mu [B][T][content_dim].
+ * out: TOKEN-MAJOR [B][T][in_channels] (the reference returns [B][in_channels][T]).  Workspace: idxtts_s2mel_cfm_workspace_bytes(ctx, B, T, 1). */
+int idxtts_s2mel_estimator(idxtts_ctx* ctx, const float* x, const float* prompt, const int* prompt_lens, int Tp_max, const int* x_lens,
+                           const float* t_emb, const float* style, const float* mu, float* out, int B, int T, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* ---- per-kernel timing for the benchmark's roofline report ------------------------------------------
  * When enabled, every kernel launch is bracketed by HIP events on its own stream and the library

@@ -4,6 +4,7 @@
 
 #include "../../include/idxtts.h"
 #include "bigvgan.h"
+#include "cond.h"
 #include "conv1d.h"
 #include "ctx.h"
 #include "gpt.h"
@@ -373,6 +374,39 @@ int idxtts_gpt_latent(idxtts_ctx* ctx, const float* emb, const int* pad_left, in
 }
 
 
+int idxtts_cond_create(const idxtts_cond_config* cfg, idxtts_ctx** out) {
+  API_BEGIN
+  IDX_CHECK(cfg && out, "null pointer");
+  std::unique_ptr<idxtts_ctx> ctx(new idxtts_ctx());
+  ctx->model.reset(new CondModel(*cfg));
+  *out = ctx.release();
+  return 0;
+  API_END
+}
+
+size_t idxtts_cond_workspace_bytes(const idxtts_ctx* ctx, int B, int T) {
+  if (!ctx || !ctx->finalized || B <= 0 || T < 3) return 0;
+  auto* m = dynamic_cast<const CondModel*>(ctx->model.get());
+  return m ? m->workspace_bytes(B, T) : 0;
+}
+
+int idxtts_cond_forward(idxtts_ctx* ctx, const float* feats, const int* lengths, int B, int T, float* out, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+  API_BEGIN
+  IDX_CHECK(ctx, "null ctx");
+  IDX_CHECK(ctx->finalized, "context not finalized");
+  auto* m = dynamic_cast<CondModel*>(ctx->model.get());
+  IDX_CHECK(m, "not a conditioning-encoder context");
+  return m->forward(feats, lengths, B, T, out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+  API_END
+}
+
+int idxtts_emovec_merge(float* out, const float* base, const float* emo, float alpha, size_t n, void* stream) {
+  API_BEGIN
+  return lerp_rows(out, base, emo, alpha, n, static_cast<hipStream_t>(stream));
+  API_END
+}
+
 int idxtts_s2mel_create(const idxtts_s2mel_config* cfg, idxtts_ctx** out) {
   API_BEGIN
   IDX_CHECK(cfg && out, "null pointer");
@@ -418,6 +452,16 @@ int idxtts_s2mel_cfm(idxtts_ctx* ctx, const float* mu, const int* x_lens, const 
   S2MEL_MODEL(ctx);
   return m->cfm(mu, x_lens, prompt, prompt_lens, Tp_max, style, z, t_emb, dt, n_steps, cfg_rate, out, B, T, workspace,
                 workspace_bytes, static_cast<hipStream_t>(stream));
+  API_END
+}
+
+int idxtts_s2mel_estimator(idxtts_ctx* ctx, const float* x, const float* prompt, const int* prompt_lens, int Tp_max, const int* x_lens,
+                           const float* t_emb, const float* style, const float* mu, float* out, int B, int T, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  API_BEGIN
+  S2MEL_MODEL(ctx);
+  return m->estimator(x, prompt, prompt_lens, Tp_max, x_lens, t_emb, style, mu, out, B, T, workspace, workspace_bytes,
+                      static_cast<hipStream_t>(stream));
   API_END
 }
 

@@ -41,6 +41,11 @@ struct GemmArgs {
   int taps = 1, seq_len = 0, dil = 1, pad_left = 0, pad_mode = 0;
   // optional output row mask: rows with (m % seq_len) >= row_len[m / seq_len] are written as 0 (x * x_mask)
   const int* row_len = nullptr;
+  // exact-fp32 kernel only: split the K loop over `ksplit` workgroups per output tile (skinny GEMMs with a very long K:
+  // the conformer's input projection, K = 261 632).  y then receives ksplit raw partial slabs [ksplit][M][ldy] -- no bias,
+  // activation or residual -- which the caller sums in a fixed order (rows_norm_forward partials), so results stay
+  // bitwise reproducible.
+  int ksplit = 1;
 };
 
 int gemm_tn_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t stream);      // exact fp32 MFMA

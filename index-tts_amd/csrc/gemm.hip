@@ -136,11 +136,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmKP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-  const int ksteps = (p.kc16 + 1) >> 1;
-  load_tiles(0);
-  store_tiles(0);
+  int ksteps = (p.kc16 + 1) >> 1, ks0 = 0;
+  if (p.ksplit > 1) { ks0 = blockIdx.y * p.ksteps_per_split; ksteps = min(ksteps, ks0 + p.ksteps_per_split); }
+  load_tiles(ks0);
+  store_tiles(ks0 & 1);
   __syncthreads();
-  for (int ks = 0; ks < ksteps; ++ks) {
+  for (int ks = ks0; ks < ksteps; ++ks) {
     const bool has_next = ks + 1 < ksteps;
     if (has_next) load_tiles(ks + 1);
     const float* xb = Xs[ks & 1];
@@ -167,6 +168,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmKP p) {
     __syncthreads();
   }
 
+  if (p.ksplit > 1) {      // raw partial slab of this K range
+    GemmKP q = p;
+    q.y = p.y + (size_t)blockIdx.y * p.M * p.ldy;
+    q.bias = nullptr; q.res = nullptr; q.row_len = nullptr; q.act = ACT_NONE; q.out_scale = 1.0f;
+    gemm_epilogue(q, acc, bm, bn, wm, wn, h, j);
+    return;
+  }
   gemm_epilogue(p, acc, bm, bn, wm, wn, h, j);
 }
 
@@ -192,6 +200,12 @@ int gemm_tn_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t strea
   p.act = a.act; p.out_scale = a.out_scale;
   p.taps = a.taps; p.kc = w.K / std::max(1, a.taps); p.seq_len = a.seq_len > 0 ? a.seq_len : 1; p.dil = a.dil; p.pad_left = a.pad_left;
   p.pad_mode = a.pad_mode; p.row_len = a.row_len;
+  p.ksplit = std::max(1, a.ksplit);
+  p.ksteps_per_split = cdiv(cdiv(p.kc16, 2), p.ksplit);
+  if (p.ksplit > 1) {
+    IDX_CHECK(a.taps <= 1 && a.act == ACT_NONE && !a.res && !a.row_len, "split-K launches produce raw partial slabs");
+    IDX_CHECK((p.ksplit - 1) * p.ksteps_per_split < cdiv(p.kc16, 2), "ksplit leaves an empty K range");
+  }
   const int nblocks = cdiv(w.N, 128);
   p.nblocks = nblocks;
   p.n_fast = ((double)w.N * w.K * 4.0 <= 8.0 * 1024 * 1024) && ((double)a.M * w.K > (double)w.N * w.K) ? 1 : 0;
@@ -206,7 +220,7 @@ int gemm_tn_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t strea
     IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)grid), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)grid, (unsigned)p.ksplit), dim3(256), lds, stream, p);
   IDX_LAUNCH_CHECK();
   return 0;
 }

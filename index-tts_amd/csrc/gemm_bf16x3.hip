@@ -384,6 +384,8 @@ int gemm_bf16x3_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t s
   p.act = a.act; p.out_scale = a.out_scale;
   p.taps = a.taps; p.kc = w.K / std::max(1, a.taps); p.seq_len = a.seq_len > 0 ? a.seq_len : 1; p.dil = a.dil; p.pad_left = a.pad_left;
   p.pad_mode = a.pad_mode; p.row_len = a.row_len;
+  p.ksplit = 1; p.ksteps_per_split = 0;
+  IDX_CHECK(a.ksplit <= 1, "split-K is a feature of the exact-fp32 kernel");
   const int nblocks = cdiv(w.N, 128);
   p.nblocks = nblocks;
   p.n_fast = ((double)w.N * w.K * 4.0 <= 8.0 * 1024 * 1024) && (a.M > w.N) ? 1 : 0;

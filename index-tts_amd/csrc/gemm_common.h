@@ -20,6 +20,7 @@ struct GemmKP {
   // optional fused rotary embedding (gemm_epilogue_lds only): columns < rope_cols are (even, odd) pairs rotated by
   // rope[(m % rope_T)][(col / 2) % 32] = (cos, sin)   (gpt_fast/model.py apply_rotary_emb on q and k of a fused qkv)
   const float* rope; int rope_T; int rope_cols;
+  int ksplit, ksteps_per_split;    // exact-fp32 kernel: K loop split over blockIdx.y (raw partial slabs)
 };
 
 

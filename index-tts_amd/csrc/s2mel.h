@@ -45,6 +45,8 @@ struct S2MelModel : ModelBase {
   int cfm(const float* mu, const int* x_lens_host, const float* prompt, const int* prompt_lens_host, int Tp_max, const float* style,
           const float* z, const float* t_emb, const float* dt_host, int n_steps, float cfg_rate, float* out, int B, int T,
           void* ws, size_t ws_bytes, hipStream_t st);
+  int estimator(const float* x, const float* prompt, const int* prompt_lens_host, int Tp_max, const int* x_lens_host, const float* t_emb,
+                const float* style, const float* mu, float* out_tm, int B, int T, void* ws, size_t ws_bytes, hipStream_t st);
   size_t cond_workspace_bytes(int B, int M, int Tg) const;
   int prepare_cond(const float* latent, const long long* codes, const int* code_lens_host, const int* target_lens_host, int B, int M,
                    int Tg, float* cond_out, void* ws, size_t ws_bytes, hipStream_t st);

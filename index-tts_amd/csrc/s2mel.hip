@@ -489,6 +489,42 @@ int S2MelModel::cfm(const float* mu, const int* x_lens_host, const float* prompt
   return 0;
 }
 
+// One evaluation of the CFM estimator = DiT.forward(x, prompt_x, x_lens, t, style, cond) (diffusion_transformer.py:186-257)
+// on B rows: the conditional half of the stacked [cond | null] evaluation the Euler loop runs every step.
+int S2MelModel::estimator(const float* x, const float* prompt, const int* prompt_lens_host, int Tp_max, const int* x_lens_host,
+                          const float* t_emb, const float* style, const float* mu, float* out_tm, int B, int T, void* ws, size_t ws_bytes,
+                          hipStream_t st) {
+  IDX_CHECK(x && prompt && prompt_lens_host && x_lens_host && t_emb && style && mu && out_tm, "null pointer");
+  IDX_CHECK(B > 0 && T > 0 && Tp_max > 0 && T <= rope_len, "shape");
+  IDX_CHECK(ws && ws_bytes >= cfm_workspace_bytes(B, T, 1), "workspace too small");
+  const int D = cfg.hidden_dim, C = cfg.in_channels, Wh = cfg.wn_hidden, depth = cfg.depth, L = cfg.wn_layers;
+  CfmBuffers w = carve_cfm(*this, ws, B, T, 1);
+  std::vector<int> lens2(2 * B), plen(B);
+  for (int b = 0; b < B; ++b) {
+    IDX_CHECK(x_lens_host[b] > 0 && x_lens_host[b] <= T && prompt_lens_host[b] >= 0 && prompt_lens_host[b] <= std::min(Tp_max, T), "lengths");
+    lens2[b] = lens2[B + b] = x_lens_host[b];
+    plen[b] = prompt_lens_host[b];
+  }
+  IDX_HIP(hipMemcpyAsync(w.lens2, lens2.data(), 2 * B * sizeof(int), hipMemcpyHostToDevice, st));
+  IDX_HIP(hipMemcpyAsync(w.plen, plen.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
+  IDX_HIP(hipStreamSynchronize(st));
+  if (gemm(temb0, t_emb, 256, w.tmp_steps, D, 1, st, ACT_SILU) || gemm(temb2, w.tmp_steps, D, w.t1, D, 1, st)) return 1;
+  if (gemm(mod_all, w.t1, D, w.mods, (2 * depth + 1) * 2 * D, 1, st)) return 1;
+  if (silu_rows(w.t1s, w.t1, (size_t)D, st) || gemm(final_mod, w.t1s, Wh, w.fmod, 2 * Wh, 1, st)) return 1;
+  if (gemm(t2emb0, t_emb, 256, w.tmp_steps, Wh, 1, st, ACT_SILU) || gemm(t2emb2, w.tmp_steps, Wh, w.t2, Wh, 1, st)) return 1;
+  if (gemm(wn_cond, w.t2, Wh, w.wnb, L * 2 * Wh, 1, st)) return 1;
+  if (gemm(cond_proj, mu, cfg.content_dim, w.condp, D, B * T, st)) return 1;
+  IDX_HIP(hipMemcpyAsync(w.xstate, x, (size_t)B * C * T * sizeof(float), hipMemcpyDeviceToDevice, st));
+  CfmPackArgs pk;
+  pk.x_in = w.x_in; pk.ld = 2 * C + D + cfg.style_dim; pk.x = w.xstate; pk.prompt = prompt; pk.prompt_len = w.plen;
+  pk.cond = w.condp; pk.cond_null = cond_proj.bias; pk.style = style;
+  pk.B = B; pk.T = T; pk.C = C; pk.D = D; pk.S = cfg.style_dim; pk.Tp_max = Tp_max;
+  if (cfm_pack(pk, st)) return 1;
+  if (dit_eval(*this, w, 2 * B, T, 0, st)) return 1;
+  IDX_HIP(hipMemcpyAsync(out_tm, w.vout, (size_t)B * T * C * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 struct CondBuffers { float *a, *b, *s, *stats; int *idx_code, *idx_row, *idx_interp, *tlen; size_t bytes; };
 

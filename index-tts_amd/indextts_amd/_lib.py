@@ -24,6 +24,7 @@ SYMBOLS = [
     "idxtts_gpt_create", "idxtts_gpt_quantize_weights", "idxtts_gpt_workspace_bytes", "idxtts_gpt_embed", "idxtts_gpt_generate", "idxtts_gpt_generate_sampled", "idxtts_gpt_latent",
     "idxtts_s2mel_create", "idxtts_s2mel_cond_workspace_bytes", "idxtts_s2mel_prepare_cond",
     "idxtts_s2mel_cfm_workspace_bytes", "idxtts_s2mel_cfm", "idxtts_set_gemm_mode", "idxtts_get_gemm_mode",
+    "idxtts_s2mel_estimator", "idxtts_cond_create", "idxtts_cond_workspace_bytes", "idxtts_cond_forward", "idxtts_emovec_merge",
 ]
 
 
@@ -43,6 +44,12 @@ class GPTConfigC(ctypes.Structure):
 
 class SamplingC(ctypes.Structure):          # idxtts_sampling (include/idxtts.h)
     _fields_ = [("mode", c_int), ("temperature", c_float), ("top_k", c_int), ("top_p", c_float), ("exp_noise", c_void_p)]
+
+
+class CondConfigC(ctypes.Structure):         # idxtts_cond_config (include/idxtts.h)
+    _fields_ = [(n, c_int) for n in ("input_size", "output_size", "linear_units", "attention_heads", "num_blocks", "cnn_kernel",
+                                     "perceiver_dim", "num_latents", "perceiver_depth", "perceiver_dim_head", "perceiver_mult",
+                                     "emotion", "model_dim")]
 
 
 class S2MelConfigC(ctypes.Structure):
@@ -116,6 +123,13 @@ def load() -> ctypes.CDLL:
     lib.idxtts_s2mel_cfm_workspace_bytes.restype = c_size_t
     lib.idxtts_s2mel_cfm.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]
+    lib.idxtts_s2mel_estimator.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int, c_int, c_void_p, c_size_t, c_void_p]
+    lib.idxtts_cond_create.argtypes = [POINTER(CondConfigC), POINTER(c_void_p)]
+    lib.idxtts_cond_workspace_bytes.argtypes = [c_void_p, c_int, c_int]
+    lib.idxtts_cond_workspace_bytes.restype = c_size_t
+    lib.idxtts_cond_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.idxtts_emovec_merge.argtypes = [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]
     lib.idxtts_profile_enable.argtypes = [c_int]
     lib.idxtts_profile_kernel_name.argtypes = [c_int]
     lib.idxtts_profile_kernel_name.restype = c_char_p

@@ -131,6 +131,36 @@ class S2Mel:
                                         float(inference_cfg_rate), _lib.ptr(out), B, T, _lib.ptr(ws), ws.numel(), _lib.current_stream()))
         return out
 
+    def estimator(self, x: torch.Tensor, prompt_x: torch.Tensor, x_lens, t: torch.Tensor, style: torch.Tensor, cond: torch.Tensor,
+                  prompt_lens=None) -> torch.Tensor:
+        """`cfm.estimator(x, prompt_x, x_lens, t, style, cond)` = DiT.forward (diffusion_transformer.py:186-257): x, prompt_x
+        [B,80,T] (prompt_x zero beyond the prompt), x_lens [B], t [B] (one shared timestep), style [B,192], cond [B,T,512]
+        -> [B,80,T].  prompt_lens: valid prompt frames per row (default: up to the last non-zero column of prompt_x)."""
+        lib = _lib.load()
+        x = x.to(self.device, torch.float32).contiguous()
+        px = prompt_x.to(self.device, torch.float32).contiguous()
+        B, C, T = x.shape
+        tt = torch.as_tensor(t).detach().cpu().float().reshape(-1)
+        if not bool((tt == tt[0]).all()):
+            raise ValueError("the estimator is evaluated at one timestep for the whole batch")
+        if prompt_lens is None:
+            nz = (px != 0).any(dim=1).cpu()
+            prompt_lens = [int(r.nonzero().max()) + 1 if bool(r.any()) else 0 for r in nz]
+        pl = np.ascontiguousarray(torch.as_tensor(prompt_lens).detach().cpu().reshape(-1).numpy(), dtype=np.int32)
+        xl = np.ascontiguousarray(torch.as_tensor(x_lens).detach().cpu().reshape(-1).numpy(), dtype=np.int32)
+        half = 128       # TimestepEmbedder.timestep_embedding (diffusion_transformer.py:38-54), scale 1000
+        freqs = torch.exp(-math.log(10000) * torch.arange(start=0, end=half, dtype=torch.float32) / half)
+        args = 1000 * tt[:1, None] * freqs[None]
+        t_emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).contiguous().to(self.device)
+        mu = cond.to(self.device, torch.float32).contiguous()
+        st = style.to(self.device, torch.float32).contiguous()
+        out = torch.empty(B, T, C, device=self.device, dtype=torch.float32)
+        ws = self._workspace(int(lib.idxtts_s2mel_cfm_workspace_bytes(self._h, B, T, 1)))
+        _lib.check(lib.idxtts_s2mel_estimator(self._h, _lib.ptr(x), _lib.ptr(px), pl.ctypes.data_as(c_void_p), T, xl.ctypes.data_as(c_void_p),
+                                              _lib.ptr(t_emb), _lib.ptr(st), _lib.ptr(mu), _lib.ptr(out), B, T, _lib.ptr(ws), ws.numel(),
+                                              _lib.current_stream()))
+        return out.transpose(1, 2)
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):

@@ -104,11 +104,24 @@ def synth_gpt_weights(cfg: GPTConfig, tag: str = "gpt") -> Weights:
     return w
 
 
+def conformer_pe(max_len: int, d_model: int) -> np.ndarray:
+    """PositionalEncoding.__init__ (indextts/gpt/conformer/embedding.py:45-53), same torch ops in the same order."""
+    import math
+    import torch
+    pe = torch.zeros(max_len, d_model)
+    position = torch.arange(0, max_len).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2) * -(math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe.unsqueeze(0).numpy()
+
+
 def synth_gpt_cond_weights(cfg: GPTConfig, tag: str = "gpt") -> Weights:
     """Keys/shapes of the prompt-conditioning half of `UnifiedVoice.state_dict()` (model_v2.py:396-423):
     `conditioning_encoder.*` / `emo_conditioning_encoder.*` (ConformerEncoder, conformer_encoder.py:436-520),
     `perceiver_encoder.*` / `emo_perceiver_encoder.*` (PerceiverResampler, perceiver.py:193-245), `emovec_layer`, `emo_layer`.
-    The sinusoid buffer `embed.pos_enc.pe` is not a weight: consumers rebuild it (embedding.py:45-53)."""
+    The sinusoid buffer `embed.pos_enc.pe` [1, 5000, D] is part of the reference's state_dict too; it is built here with the
+    reference's own torch expression (embedding.py:45-53) so that it is bit-identical."""
     w: Weights = {}
     d = cfg.model_dim
 
@@ -126,6 +139,7 @@ def synth_gpt_cond_weights(cfg: GPTConfig, tag: str = "gpt") -> Weights:
 
     def conformer(p, m):
         D, hd = m.output_size, m.output_size // m.attention_heads
+        w[f"{p}.embed.pos_enc.pe"] = conformer_pe(5000, D)
         w[f"{p}.embed.conv.0.weight"] = synth.fan_in_uniform(f"{tag}/{p}.embed.conv.0.weight", (D, 1, 3, 3), 9, 1.5)
         u(f"{p}.embed.conv.0.bias", (D,), 0.3)
         lin(f"{p}.embed.out.0", D, D * m.sub_freq, 1.6)

@@ -228,6 +228,141 @@ def generate_sample(w, cfg, conds: torch.Tensor, text_inputs: torch.Tensor, max_
     return input_ids[:, P + 1:]
 
 
+class _BeamHyps:
+    """BeamHypotheses (indextts/gpt/transformers_beam_search.py:930-1013): n-best list of finished hypotheses."""
+
+    def __init__(self, num_beams: int, length_penalty: float, early_stopping: bool):
+        self.num_beams, self.length_penalty, self.early_stopping = num_beams, length_penalty, early_stopping
+        self.beams = []
+        self.worst_score = 1e9
+
+    def add(self, hyp: torch.Tensor, sum_logprobs: float, generated_len: int):
+        score = sum_logprobs / (generated_len ** self.length_penalty)
+        if len(self.beams) < self.num_beams or score > self.worst_score:
+            self.beams.append((score, hyp))
+            if len(self.beams) > self.num_beams:
+                ranked = sorted([(s, idx) for idx, (s, _) in enumerate(self.beams)])
+                del self.beams[ranked[0][1]]
+                self.worst_score = ranked[1][0]
+            else:
+                self.worst_score = min(score, self.worst_score)
+
+    def is_done(self, best_sum_logprobs: float, cur_len: int, prompt_len: int) -> bool:
+        if len(self.beams) < self.num_beams:
+            return False
+        if self.early_stopping is True:
+            return True
+        return self.worst_score >= best_sum_logprobs / (cur_len - prompt_len) ** self.length_penalty
+
+
+def generate_beam(w, cfg, conds: torch.Tensor, text_inputs: torch.Tensor, max_new_tokens: int, exp_noise: Optional[torch.Tensor],
+                  num_beams: int = 3, repetition_penalty_value: float = 10.0, temperature: float = 0.8, top_k: int = 30,
+                  top_p: float = 0.8, length_penalty: float = 0.0, do_sample: bool = True, early_stopping: bool = False,
+                  return_trace: bool = False):
+    """inference_speech (model_v2.py:835-892) with num_beams > 1 -- the mode `IndexTTS2.infer` really runs by default
+    (infer_v2.py:714-722, 767: do_sample=True, num_beams=3, top_p=.8, top_k=30, temperature=.8, repetition_penalty=10,
+    length_penalty=0).  Restates the vendored `GenerationMixin._beam_search` (transformers_generation_utils.py:3325-3516):
+      log_softmax(fp32 logits) BEFORE the processors (3473-3477); processors = repetition penalty then, when sampling, the
+      warpers with min_tokens_to_keep = 2 (1022-1029); + running beam scores (first beam 0, the others -1e9: 3420-3422);
+      2 * num_beams candidates over the num_beams * V flattened scores -- `torch.multinomial` without replacement
+      (3509-3510: ATen draws q ~ Exp(1) ONCE for the [B, num_beams * V] tensor and takes topk(probs / q), so the draw is the
+      explicit input exp_noise[step]) re-sorted by score (3511-3513), or plain top-k when do_sample=False (3517-3519);
+      BeamSearchScorer.process / finalize (transformers_beam_search.py:215-318, 320-414) with BeamHypotheses above; the KV
+      cache re-indexed by beam_idx every step (`_reorder_cache`, model_v2.py:227-240).
+    Returns codes [B, n] (best hypothesis per utterance, eos appended when it fits, stop-token padded)."""
+    fake, inputs_embeds, attention_mask = prepare_gpt_inputs(w, cfg, conds, text_inputs)
+    B, P, d = inputs_embeds.shape
+    nb, V = num_beams, cfg.number_mel_codes
+    eos = pad = cfg.stop_mel_token
+    me, mp = _t(w, "mel_embedding.weight"), _t(w, "mel_pos_embedding.emb.weight")
+    input_ids = fake.repeat_interleave(nb, 0)                       # _expand_inputs_for_generation
+    attention_mask = attention_mask.repeat_interleave(nb, 0)
+    embeds = inputs_embeds.repeat_interleave(nb, 0)                 # model_v2.py:166-169
+    prompt_len = input_ids.shape[1]
+    max_length = prompt_len + max_new_tokens
+    beam_scores = torch.zeros(B, nb)
+    beam_scores[:, 1:] = -1e9
+    beam_scores = beam_scores.view(-1)
+    hyps = [_BeamHyps(nb, length_penalty, early_stopping) for _ in range(B)]
+    done = [False] * B
+    past = None
+    step = 0
+    trace = []
+    while True:
+        if past is None:
+            start = (me[cfg.start_mel_token] + mp[0])[None, None, :].expand(B * nb, 1, d)
+            emb = torch.cat([embeds, start], dim=1)
+        else:
+            emb = (me[input_ids[:, -1]] + mp[attention_mask.shape[1] - P])[:, None, :]
+        hidden, past = gpt2_stack(w, cfg, emb, attention_mask, past)
+        logits = lm_head(w, cfg, hidden[:, -1]).float()
+        scores = F.log_softmax(logits, dim=-1)
+        proc = repetition_penalty(input_ids, scores, repetition_penalty_value) if repetition_penalty_value != 1.0 else scores
+        if do_sample:
+            proc = warp_scores(proc, temperature, top_k, top_p, min_tokens_to_keep=2)
+        scores = (proc + beam_scores[:, None]).view(B, nb * V)
+        n_keep = 2 * nb
+        if do_sample:
+            probs = F.softmax(scores, dim=-1)
+            cand = torch.topk(probs / exp_noise[step].float(), n_keep, dim=-1)[1]       # == torch.multinomial(probs, n_keep)
+            cand_scores = torch.gather(scores, -1, cand)
+            cand_scores, order = torch.sort(cand_scores, descending=True, dim=1)
+            cand = torch.gather(cand, -1, order)
+        else:
+            cand_scores, cand = torch.topk(scores, n_keep, dim=1, largest=True, sorted=True)
+        cand_beam = torch.div(cand, V, rounding_mode="floor")
+        cand_tok = cand % V
+        # ---- BeamSearchScorer.process ----
+        cur_len = input_ids.shape[-1] + 1
+        nxt_scores = torch.zeros(B, nb)
+        nxt_tok = torch.zeros(B, nb, dtype=torch.long)
+        nxt_idx = torch.zeros(B, nb, dtype=torch.long)
+        for b in range(B):
+            if done[b]:
+                nxt_tok[b, :] = pad
+                continue
+            slot = 0
+            for rank in range(n_keep):
+                tok, sc, src = int(cand_tok[b, rank]), float(cand_scores[b, rank]), b * nb + int(cand_beam[b, rank])
+                if tok == eos:
+                    if rank >= nb:
+                        continue
+                    hyps[b].add(input_ids[src].clone(), sc, cur_len - prompt_len)
+                else:
+                    nxt_scores[b, slot], nxt_tok[b, slot], nxt_idx[b, slot] = sc, tok, src
+                    slot += 1
+                if slot == nb:
+                    break
+            assert slot == nb, "fewer than num_beams non-eos candidates"
+            done[b] = done[b] or hyps[b].is_done(float(cand_scores[b].max()), cur_len, prompt_len)
+        beam_scores = nxt_scores.view(-1)
+        beam_idx = nxt_idx.view(-1)
+        if return_trace:
+            trace.append((beam_idx.clone(), nxt_tok.view(-1).clone(), beam_scores.clone()))
+        input_ids = torch.cat([input_ids[beam_idx], nxt_tok.view(-1, 1)], dim=-1)
+        past = [(k.index_select(0, beam_idx), v.index_select(0, beam_idx)) for k, v in past]
+        attention_mask = torch.cat([attention_mask, torch.ones(B * nb, 1, dtype=torch.long)], dim=1)
+        step += 1
+        if all(done) or input_ids.shape[-1] >= max_length:
+            break
+    # ---- BeamSearchScorer.finalize ----
+    for b in range(B):
+        if done[b]:
+            continue
+        for j in range(nb):
+            hyps[b].add(input_ids[b * nb + j], float(beam_scores[b * nb + j]), input_ids.shape[-1] - prompt_len)
+    best = [sorted(h.beams, key=lambda x: x[0]).pop()[1] for h in hyps]
+    lens = [len(x) for x in best]
+    sent_max = min(max(lens) + 1, max_length)
+    decoded = torch.full((B, sent_max), pad, dtype=torch.long)
+    for b, hyp in enumerate(best):
+        decoded[b, :lens[b]] = hyp
+        if lens[b] < sent_max:
+            decoded[b, lens[b]] = eos
+    codes = decoded[:, prompt_len:]
+    return (codes, trace) if return_trace else codes
+
+
 def latent_forward(w, cfg, speech_conditioning_latent: torch.Tensor, text_inputs: torch.Tensor,
                    mel_codes: torch.Tensor, emo_vec: torch.Tensor,
                    text_lengths: Optional[torch.Tensor] = None,

@@ -204,6 +204,13 @@ def make_s2mel(Munch):
             S = torch.from_numpy(synth.uniform(f"golden/s2mel/S_{tag}", (1, M, cfg.lr_in_channels), 1.0))
             ylens = (torch.LongTensor([M]) * 1.72).long()
             out[f"lr_{tag}"] = mm.models["length_regulator"](S, ylens=ylens, n_quantizers=3, f0=None)[0].numpy()
+        # (c2) the composed call of infer_v2.py:835-849 per utterance: length_regulator(vq2emb(codes) + gpt_layer(latent))
+        for tag, M in (("a", 9), ("b", 20)):
+            lat1 = torch.from_numpy(synth.uniform(f"t/s2mel/lat_{tag}", (1, M, cfg.gpt_dim), 1.0))
+            codes1 = torch.from_numpy(synth.integers(f"t/s2mel/codes_{tag}", (1, M), 0, cfg.codebook_size))
+            S = fvq.vq2emb(codes1).transpose(1, 2) + mm.models["gpt_layer"](lat1)
+            ylens = (torch.LongTensor([M]) * 1.72).long()
+            out[f"cond_{tag}"] = mm.models["length_regulator"](S, ylens=ylens, n_quantizers=3, f0=None)[0].numpy()
         # (d) one DiT forward, N=2 rows with different x_lens (exercises the key-padding mask and the WaveNet mask)
         T = 37
         x = torch.from_numpy(synth.uniform("golden/s2mel/dit/x", (2, cfg.in_channels, T), 1.0))
@@ -213,6 +220,10 @@ def make_s2mel(Munch):
         mu = torch.from_numpy(synth.uniform("golden/s2mel/dit/mu", (2, T, cfg.content_dim), 1.0))
         tt = torch.tensor([0.35, 0.35])
         out["dit"] = est(x, px, torch.LongTensor([T, T - 6]), tt, st, mu).numpy()
+        # the second row ALONE at its own length (the only way infer_v2 ever calls the estimator: B = 1, x_lens = T): what a
+        # ragged batch must reproduce for that row, reflect padding of the WaveNet convolutions at the row's own end included
+        out["dit_row1_alone"] = est(x[1:2, :, :T - 6].contiguous(), px[1:2, :, :T - 6].contiguous(), torch.LongTensor([T - 6]), tt[:1], st[1:2],
+                                    mu[1:2, :T - 6].contiguous()).numpy()
         # (e) CFM Euler with CFG, B=1 (the reference's only mode), Tp=11 prompt frames + 23 generated, 3 steps
         Tp, Tg = 11, 23
         T = Tp + Tg
@@ -417,6 +428,84 @@ def build_reference_unified_voice(mv, cfg, w):
     return uv.eval()
 
 
+def _import_reference_beam_scorer():
+    """The reference's vendored `BeamSearchScorer` / `BeamHypotheses` (indextts/gpt/transformers_beam_search.py:123-420,
+    930-1013).  Its only missing import, `transformers.generation.beam_constraints`, serves the constrained scorer, which is
+    never used: inert placeholder."""
+    import importlib.util
+    bc = types.ModuleType("transformers.generation.beam_constraints")
+    bc.Constraint = object
+    bc.ConstraintListState = object
+    sys.modules.setdefault("transformers.generation.beam_constraints", bc)
+    spec = importlib.util.spec_from_file_location("ref_transformers_beam_search", os.path.join(REF, "indextts/gpt/transformers_beam_search.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def drive_vendored_beam_search(uv, scorer_mod, cfg, conds, text, max_new, num_beams, do_sample, temperature, top_k, top_p,
+                               repetition_penalty, length_penalty):
+    """The vendored `GenerationMixin._beam_search` loop (transformers_generation_utils.py:3325-3516; that module cannot be
+    imported under transformers 5.x) driven by hand, statement for statement, around code that DOES run: the reference's
+    `GPT2InferenceModel.prepare_inputs_for_generation` / `forward`, this image's HF logits processors (the classes lines
+    900-901, 1034-1043 instantiate) and the reference's vendored `BeamSearchScorer.process` / `finalize`.  Sampling goes
+    through `torch.multinomial` on the global RNG exactly as line 3510 does."""
+    from transformers.generation.logits_process import (LogitsProcessorList, RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper,
+                                                        TopKLogitsWarper, TopPLogitsWarper)
+    im = uv.inference_model
+    fake, inputs_embeds, attention_mask = uv.prepare_gpt_inputs(conds, text)
+    im.store_mel_emb(inputs_embeds)
+    B = fake.shape[0]
+    procs = LogitsProcessorList([RepetitionPenaltyLogitsProcessor(penalty=repetition_penalty)])
+    if do_sample:
+        procs += [TemperatureLogitsWarper(temperature), TopKLogitsWarper(top_k=top_k, min_tokens_to_keep=2),
+                  TopPLogitsWarper(top_p=top_p, min_tokens_to_keep=2)]
+    eos = torch.tensor([cfg.stop_mel_token])
+    max_length = fake.shape[1] + max_new
+    scorer = scorer_mod.BeamSearchScorer(batch_size=B, num_beams=num_beams, device=fake.device, length_penalty=length_penalty,
+                                         do_early_stopping=False, num_beam_hyps_to_keep=1, max_length=max_length)
+    input_ids = fake.repeat_interleave(num_beams, 0)
+    mask = attention_mask.repeat_interleave(num_beams, 0)
+    beam_scores = torch.zeros((B, num_beams), dtype=torch.float)
+    beam_scores[:, 1:] = -1e9
+    beam_scores = beam_scores.view((B * num_beams,))
+    prompt_len = input_ids.shape[-1]
+    past = None
+    with torch.no_grad():
+        while True:
+            mi = im.prepare_inputs_for_generation(input_ids, past_key_values=past, attention_mask=mask, use_cache=True)
+            o = im(**mi, return_dict=True)
+            past = o.past_key_values
+            mask = torch.cat([mask, mask.new_ones((mask.shape[0], 1))], dim=-1)
+            next_token_logits = o.logits[:, -1, :].clone().float()
+            next_token_scores = torch.nn.functional.log_softmax(next_token_logits, dim=-1)
+            processed = procs(input_ids, next_token_scores)
+            next_token_scores = processed + beam_scores[:, None].expand_as(processed)
+            vocab = next_token_scores.shape[-1]
+            next_token_scores = next_token_scores.view(B, num_beams * vocab)
+            n_keep = max(2, 1 + 1) * num_beams
+            if do_sample:
+                probs = torch.nn.functional.softmax(next_token_scores, dim=-1)
+                next_tokens = torch.multinomial(probs, num_samples=n_keep)
+                next_token_scores = torch.gather(next_token_scores, -1, next_tokens)
+                next_token_scores, _indices = torch.sort(next_token_scores, descending=True, dim=1)
+                next_tokens = torch.gather(next_tokens, -1, _indices)
+            else:
+                next_token_scores, next_tokens = torch.topk(next_token_scores, n_keep, dim=1, largest=True, sorted=True)
+            next_indices = torch.div(next_tokens, vocab, rounding_mode="floor")
+            next_tokens = next_tokens % vocab
+            bo = scorer.process(input_ids, next_token_scores, next_tokens, next_indices, pad_token_id=cfg.stop_mel_token,
+                                eos_token_id=eos, beam_indices=None, decoder_prompt_len=prompt_len)
+            beam_scores, beam_next, beam_idx = bo["next_beam_scores"], bo["next_beam_tokens"], bo["next_beam_indices"]
+            input_ids = torch.cat([input_ids[beam_idx, :], beam_next.unsqueeze(-1)], dim=-1)
+            past = im._reorder_cache(past, beam_idx)                      # model_v2.py:227-240
+            if scorer.is_done or input_ids.shape[-1] >= max_length:
+                break
+        seq = scorer.finalize(input_ids, beam_scores, next_tokens, next_indices, pad_token_id=cfg.stop_mel_token, eos_token_id=eos,
+                              max_length=max_length, beam_indices=None, decoder_prompt_len=prompt_len)["sequences"]
+    return seq[:, prompt_len:]
+
+
 def make_gpt_ref():
     """GPT fixtures produced by the REFERENCE's own `UnifiedVoice` / `GPT2InferenceModel` code (model_v2.py), imported from
     /root/reference: conditioning encoders, emotion vector, prompt layout, cached decode forward, latent pass and -- through
@@ -525,6 +614,43 @@ def make_gpt_ref():
     out["latent_text"] = text2.numpy()
     out["latent_codes"] = codes2.numpy()
     out["latent"] = latent.numpy()
+    # ---- f2: beam search, the mode infer() really runs by default (infer_v2.py:714-722, 767): num_beams=3, do_sample=True,
+    #      top_p .8, top_k 30, temperature .8, repetition_penalty 10, length_penalty 0 -- the reference's inference_speech
+    #      driven by this image's HF generate, seeded; the Exp(1) draws torch.multinomial consumed are re-drawn with the same
+    #      seed and stored.  mel_head's stop bias is raised so that some hypotheses finish (exercises BeamHypotheses) ----
+    from oracle import gpt as og
+    from transformers.cache_utils import DynamicCache
+    NB, NEWB, SEED = 3, 24, 1234
+    scorer_mod = _import_reference_beam_scorer()
+    for tag, stop_bias in (("a", 3.0), ("b", 5.5)):
+        wb = dict(w)
+        wb["mel_head.bias"] = w["mel_head.bias"].copy()
+        wb["mel_head.bias"][cfg.stop_mel_token] += stop_bias
+        uvb = build_reference_unified_voice(mv, cfg, wb)
+        twb = {k: torch.from_numpy(v) for k, v in wb.items()}
+        for mode, do_sample in (("det", False), ("sample", True)):
+            torch.manual_seed(SEED)
+            with torch.no_grad(), quiet():
+                codes, _ = uvb.inference_speech(spk, text, emo, cond_lengths=ln_spk, emo_cond_lengths=ln_emo, emo_vec=emovec.expand(B, -1),
+                                                num_return_sequences=1, max_generate_length=NEWB, do_sample=do_sample, top_p=0.8, top_k=30,
+                                                temperature=0.8, length_penalty=0.0, num_beams=NB, repetition_penalty=10.0,
+                                                past_key_values=DynamicCache())
+            # the same decode through the vendored loop + the reference's own BeamSearchScorer: THE expected value.  Where the
+            # hypotheses finish early, transformers 5.x's rewritten beam search (no BeamScorer any more) stops by a different
+            # rule than the vendored 4.x scorer; everywhere else the two agree, which checks the hand-driven loop.
+            torch.manual_seed(SEED)
+            vend = drive_vendored_beam_search(uvb, scorer_mod, cfg, conds, text, NEWB, NB, do_sample, 0.8, 30, 0.8, 10.0, 0.0)
+            same = vend.shape == codes.shape and bool((vend == codes).all())
+            print(f"beam {tag} {mode}: vendored-scorer drive {'==' if same else '!='} transformers-5.x generate;", vend.tolist())
+            out[f"beam_{tag}_{mode}_codes"] = vend.numpy()
+            out[f"beam_{tag}_{mode}_hf5_agrees"] = np.array(same)
+            torch.manual_seed(SEED)
+            noise = torch.stack([torch.empty(B, NB * cfg.number_mel_codes).exponential_(1) for _ in range(NEWB)])
+            if do_sample:
+                out[f"beam_{tag}_noise"] = noise.numpy()
+            chk = og.generate_beam(twb, cfg, conds, text, NEWB, noise, num_beams=NB, do_sample=do_sample)
+            assert chk.shape == vend.shape and bool((chk == vend).all()), "beam-search restatement != vendored beam search on the reference model"
+        out[f"beam_{tag}_stop_bias"] = np.array(stop_bias, dtype=np.float32)
     np.savez_compressed(os.path.join(HERE, "gpt_ref.npz"), **out)
     print("wrote gpt_ref.npz", {k: v.shape for k, v in out.items()})
     return uv, cfg, w, out

@@ -1,0 +1,65 @@
+"""GPU parity of the GPT stage through the C ABI against fixtures the REFERENCE's own `UnifiedVoice` produced
+(tests/golden/make_golden.py::make_gpt_ref -> gpt_ref.npz): prompt layout (a2), cached decode logits and greedy codes (a3, a5),
+`inference_speech` end to end (a6) and the latent pass (a7)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from indextts_amd import weights
+from indextts_amd.config import GPTConfig
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ref(golden_dir, device):
+    from indextts_amd.gpt import UnifiedVoice
+    g = np.load(os.path.join(golden_dir, "gpt_ref.npz"))
+    cfg = GPTConfig.tiny()
+    w = weights.synth_gpt_weights(cfg, tag="golden/gptref")
+    return g, cfg, w, UnifiedVoice(w, cfg, device=device)
+
+
+def test_prepare_gpt_inputs_vs_reference(ref, device):
+    g, cfg, w, uv = ref
+    conds = uv.conds_latent(torch.from_numpy(g["cond_latent"]).expand(3, -1, -1), torch.from_numpy(g["emovec_merged"]).expand(3, -1))
+    np.testing.assert_array_equal(conds.cpu().numpy(), g["conds"])
+    fake, emb, mask = uv.prepare_gpt_inputs(conds, torch.from_numpy(g["text"]))
+    np.testing.assert_array_equal(fake.numpy(), g["prep_fake"])
+    np.testing.assert_array_equal(mask.numpy(), g["prep_mask"])
+    np.testing.assert_array_equal(emb.cpu().numpy(), g["prep_embeds"])
+
+
+def test_cached_decode_logits_and_codes_vs_reference(ref, device):
+    """GPT2InferenceModel.forward through its own prepare_inputs_for_generation: per-step logits and greedy codes."""
+    g, cfg, w, uv = ref
+    conds = torch.from_numpy(g["conds"]).to(device)
+    fake, emb, mask = uv.prepare_gpt_inputs(conds, torch.from_numpy(g["text"]))
+    NEW = g["step_codes"].shape[1]
+    for graph in (False, True):
+        out = uv.generate(fake, max_new_tokens=NEW, stop_tokens=[cfg.stop_mel_token], attention_mask=mask, tts_embeddings=emb,
+                          repetition_penalty=10.0, use_graph=graph)
+        np.testing.assert_array_equal(out[:, fake.shape[1]:].cpu().numpy(), g["step_codes"])
+    out, logits = uv.generate(fake, max_new_tokens=NEW, stop_tokens=[cfg.stop_mel_token], attention_mask=mask, tts_embeddings=emb,
+                              repetition_penalty=10.0, return_logits=True)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["step_logits"], rtol=0, atol=5e-4)
+
+
+def test_inference_speech_greedy_vs_reference(ref, device):
+    """UnifiedVoice.inference_speech(do_sample=False, num_beams=1, repetition_penalty=10) of the reference, end to end."""
+    g, cfg, w, uv = ref
+    codes, lat = uv.inference_speech(torch.from_numpy(g["cond_latent"]).expand(3, -1, -1), torch.from_numpy(g["text"]),
+                                     emo_vec=torch.from_numpy(g["emovec_merged"]).expand(3, -1),
+                                     max_generate_length=g["speech_greedy_codes"].shape[1], do_sample=False, num_beams=1, repetition_penalty=10.0)
+    np.testing.assert_array_equal(codes.cpu().numpy(), g["speech_greedy_codes"])
+
+
+def test_latent_pass_vs_reference(ref, device):
+    g, cfg, w, uv = ref
+    B, M = g["latent_codes"].shape
+    L = g["latent_text"].shape[1]
+    out = uv.forward(torch.from_numpy(g["cond_latent"]).expand(B, -1, -1), torch.from_numpy(g["latent_text"]), torch.tensor([L, L]),
+                     torch.from_numpy(g["latent_codes"]), torch.tensor([M, M]), emo_vec=torch.from_numpy(g["emovec_merged"]).expand(B, -1))
+    np.testing.assert_allclose(out.cpu().numpy(), g["latent"], rtol=0, atol=5e-5)

@@ -92,3 +92,19 @@ def test_latent_pass_matches_reference_forward(ref):
     lat = og.latent_forward(w, cfg, torch.from_numpy(g["cond_latent"]).expand(B, -1, -1), torch.from_numpy(g["latent_text"]),
                             torch.from_numpy(g["latent_codes"]), torch.from_numpy(g["emovec_merged"]).expand(B, -1))
     np.testing.assert_allclose(lat.numpy(), g["latent"], rtol=0, atol=5e-5)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("mode", ["det", "sample"])
+def test_beam_search_matches_reference_inference_speech(ref, tag, mode):
+    """num_beams=3 (the mode infer() runs by default, infer_v2.py:714-722): the reference's inference_speech under HF generate,
+    deterministic beams and beam-sample with the stored Exp(1) draws."""
+    g, cfg, w, _, _ = ref
+    w = dict(w)
+    w["mel_head.bias"] = w["mel_head.bias"].clone()
+    w["mel_head.bias"][cfg.stop_mel_token] += float(g[f"beam_{tag}_stop_bias"])
+    want = g[f"beam_{tag}_{mode}_codes"]
+    noise = torch.from_numpy(g[f"beam_{tag}_noise"])
+    got = og.generate_beam(w, cfg, torch.from_numpy(g["conds"]), torch.from_numpy(g["text"]), noise.shape[0], noise,
+                           num_beams=3, do_sample=(mode == "sample"))
+    np.testing.assert_array_equal(got.numpy(), want)
