@@ -189,6 +189,28 @@ typedef struct idxtts_sampling {
 int idxtts_gpt_generate_sampled(idxtts_ctx* ctx, const float* inputs_embeds, const int* pad_left, int B, int P, int max_new_tokens,
                                 float repetition_penalty, const idxtts_sampling* sampling, long long* codes, int* n_steps,
                                 float* logits_out, void* workspace, size_t workspace_bytes, int use_graph, void* stream);
+/* Beam search / beam-sample = what `IndexTTS2.infer` runs by default (infer_v2.py:714-722, 767: do_sample=True, num_beams=3,
+ * top_p .8, top_k 30, temperature .8, repetition_penalty 10, length_penalty 0) through HF `_beam_search`
+ * (transformers_generation_utils.py:3325-3516) + BeamSearchScorer (transformers_beam_search.py:123-420): log_softmax before
+ * the processors, warpers with min_tokens_to_keep = 2, 2 * num_beams candidates per utterance drawn without replacement
+ * (torch.multinomial == top-(2 num_beams) of probs / q, q ~ Exp(1): exp_noise, device fp32 [max_new_tokens][B][num_beams * V],
+ * one exponential_() per step on the [B][num_beams * V] tensor) or taken as the plain top-k (do_sample = 0), hypotheses kept
+ * per utterance, the best one returned.  codes: device int64 [B][max_new_tokens] = best hypothesis, the stop token appended when
+ * it fits, stop-token padded; *n_steps = valid columns.  B * num_beams <= 64, 2 <= num_beams <= 8. */
+typedef struct idxtts_beam {
+  int num_beams;
+  int do_sample;
+  float temperature;
+  int top_k;
+  float top_p;
+  float length_penalty;
+  int early_stopping;        /* 0 = False (heuristic, the default), 1 = True */
+  const float* exp_noise;
+} idxtts_beam;
+size_t idxtts_gpt_beam_workspace_bytes(const idxtts_ctx* ctx, int B, int num_beams, int S, int max_new_tokens);
+int idxtts_gpt_generate_beam(idxtts_ctx* ctx, const float* inputs_embeds, const int* pad_left, int B, int P, int max_new_tokens,
+                             float repetition_penalty, const idxtts_beam* beam, long long* codes, int* n_steps, void* workspace,
+                             size_t workspace_bytes, int use_graph, void* stream);
 /* Latent pass: full causal forward over emb [B][S][d]; latent[b][i] = final_norm(ln_f(h[b][mel_start + i])), i < M.
  * pad_left: optional HOST int32 [B], leading rows of each sequence that are padding (masked as keys), so rows with
  * shorter texts can share a batch and still reproduce the reference's per-utterance (B=1) result. */

@@ -365,6 +365,22 @@ int idxtts_gpt_generate_sampled(idxtts_ctx* ctx, const float* inputs_embeds, con
   API_END
 }
 
+size_t idxtts_gpt_beam_workspace_bytes(const idxtts_ctx* ctx, int B, int num_beams, int S, int max_new_tokens) {
+  if (!ctx || !ctx->finalized || B <= 0 || num_beams < 2 || S <= 0 || max_new_tokens <= 0) return 0;
+  auto* m = dynamic_cast<const GPTModel*>(ctx->model.get());
+  return m ? m->beam_workspace_bytes(B, num_beams, S, max_new_tokens) : 0;
+}
+
+int idxtts_gpt_generate_beam(idxtts_ctx* ctx, const float* inputs_embeds, const int* pad_left, int B, int P, int max_new_tokens,
+                             float repetition_penalty, const idxtts_beam* beam, long long* codes, int* n_steps, void* workspace,
+                             size_t workspace_bytes, int use_graph, void* stream) {
+  API_BEGIN
+  GPT_MODEL(ctx);
+  return m->generate_beam(inputs_embeds, pad_left, B, P, max_new_tokens, repetition_penalty, beam, codes, n_steps, workspace,
+                          workspace_bytes, use_graph, static_cast<hipStream_t>(stream));
+  API_END
+}
+
 int idxtts_gpt_latent(idxtts_ctx* ctx, const float* emb, const int* pad_left, int B, int S, int mel_start, int M, float* latent,
                       void* workspace, size_t workspace_bytes, void* stream) {
   API_BEGIN

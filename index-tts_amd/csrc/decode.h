@@ -67,6 +67,8 @@ struct GatherArgs {
   float* out = nullptr; int ld_out = 0; int d = 0;
   const float* table[GATHER_MAX_TABLES] = {};   // [n_t][d]
   const int* idx[GATHER_MAX_TABLES] = {};       // [rows], -1 = skip
+  int table_rows[GATHER_MAX_TABLES] = {};       // rows of each table (0 = not checked): an id >= table_rows is NOT read ...
+  int* oob = nullptr;                           // ... and, when given, *oob is set to 1 + table index (device int, caller zeroes it)
 };
 int gather_sum_rows(const GatherArgs& a, int rows, hipStream_t stream);
 int embed_step(float* x, int B, int d, const float* mel_emb, const float* mel_pos, const int* cur_tok, const DecodeState* st,

@@ -517,7 +517,13 @@ __global__ __launch_bounds__(256) void gather_sum_rows_kernel(const GatherArgs p
   const int r = blockIdx.x;
   int id[GATHER_MAX_TABLES];
 #pragma unroll
-  for (int t = 0; t < GATHER_MAX_TABLES; ++t) id[t] = (p.table[t] && p.idx[t]) ? p.idx[t][r] : -1;
+  for (int t = 0; t < GATHER_MAX_TABLES; ++t) {
+    id[t] = (p.table[t] && p.idx[t]) ? p.idx[t][r] : -1;
+    if (p.table_rows[t] > 0 && id[t] >= p.table_rows[t]) {      // nn.Embedding would raise IndexError: never read past the table
+      if (p.oob && threadIdx.x == 0) *p.oob = 1 + t;
+      id[t] = -1;
+    }
+  }
   for (int e = threadIdx.x; e < p.d; e += 256) {
     float v = 0.f;
 #pragma unroll

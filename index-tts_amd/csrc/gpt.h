@@ -1,6 +1,7 @@
 #pragma once
 #include "../../include/idxtts.h"
 #include "attention.h"
+#include "beam.h"
 #include "ctx.h"
 #include "decode.h"
 #include "gemm.h"
@@ -27,6 +28,7 @@ struct GPTModel : ModelBase {
   const float *mel_emb = nullptr, *text_emb = nullptr, *mel_pos = nullptr, *text_pos = nullptr;
   int weight_fmt = WFMT_F32;      // storage format of the decode weight streams (quantize_weights)
   hipStream_t own_stream = nullptr;
+  int* oob_flag = nullptr;        // device int: set by the embedding gather when an index exceeds its table
   ~GPTModel() override { if (own_stream) (void)hipStreamDestroy(own_stream); }
 
   struct Buffers {
@@ -59,10 +61,18 @@ struct GPTModel : ModelBase {
   //  each call with its own workspace and stream)
   int generate(const float* inputs_embeds, const int* pad_left_host, int B, int P, int max_new, float penalty, const idxtts_sampling* sampling, long long* codes,
                int* n_steps_out, float* logits_out, void* ws, size_t ws_bytes, int use_graph, hipStream_t st);
+  // Beam search / beam-sample (HF _beam_search; the reference's default decoding mode, infer_v2.py:714-722): B utterances x
+  // num_beams rows through the same decode step, selection / hypotheses / re-indexing on the device (beam.hip).
+  size_t beam_workspace_bytes(int B, int nb, int S, int max_new) const;
+  int generate_beam(const float* inputs_embeds, const int* pad_left_host, int B, int P, int max_new, float penalty, const idxtts_beam* beam,
+                    long long* codes, int* n_steps_out, void* ws, size_t ws_bytes, int use_graph, hipStream_t st);
   int latent(const float* emb, const int* pad_left_host, int B, int S, int mel_start, int M, float* latent_out, void* ws, size_t ws_bytes,
              hipStream_t st);
   int embed(float* out, int rows, const int* text_ids, const int* text_pos_idx, const int* mel_ids, const int* mel_pos_idx,
             const float* extra, const int* extra_idx, hipStream_t st);
 };
+
+// beam state of the generation this host thread is running (null = greedy / sampling); read by head_and_sample
+extern thread_local const BeamState* tl_beam;
 
 }  // namespace idxtts

@@ -171,6 +171,12 @@ int GPTModel::finalize(std::map<std::string, HostTensor>& t, DeviceArena& arena)
   const int d = cfg.model_dim, f = 4 * d;
   IDX_CHECK(d == cfg.heads * 64, "head_dim must be 64");
   IDX_CHECK(cfg.layers > 0 && (d & 15) == 0, "config");
+  {
+    const int zero = 0;
+    void* flag = nullptr;
+    if (arena.upload_bytes(&zero, sizeof(int), &flag)) return 1;
+    oob_flag = static_cast<int*>(flag);
+  }
   layers.resize(cfg.layers);
   for (int i = 0; i < cfg.layers; ++i) {
     GPTLayer& L = layers[i];
@@ -291,6 +297,7 @@ int GPTModel::layer_full(int li, const Buffers& w, int B, int S, const int* ksta
 
 // sampling mode of the generation this host thread is running (mode 0 = greedy)
 static thread_local idxtts_sampling samp{0, 1.0f, 0, 1.0f, nullptr};
+thread_local const BeamState* tl_beam = nullptr;
 
 // head on B rows: ln_f -> final_norm (one rows_norm launch, output as fragment images) -> mel_head -> greedy sampler
 int GPTModel::head_and_sample(const Buffers& w, int B, const float* x, int ldx, bool x_frag, float penalty, long long* codes,
@@ -303,6 +310,7 @@ int GPTModel::head_and_sample(const Buffers& w, int B, const float* x, int ldx, 
   GemvFXArgs hv;
   hv.xf = w.hd; hv.rows = B; hv.bias = head_b; hv.y = w.logits; hv.ldy = V;
   if (gemv_fx_forward(head_g, hv, st)) return 1;
+  if (tl_beam) return beam_scores_forward(*tl_beam, st) || beam_select_forward(*tl_beam, st) || beam_reorder_forward(*tl_beam, st);
   SampleArgs s;
   s.part = w.logits; s.parts = 1; s.part_rows = B; s.bias = nullptr; s.logits_out = logits_out;
   s.seen = w.seen; s.finished = w.finished; s.codes = codes; s.codes_ld = codes_ld; s.cur_tok = w.cur_tok;
@@ -516,7 +524,17 @@ int GPTModel::embed(float* out, int rows, const int* text_ids, const int* text_p
   ga.table[2] = mel_emb; ga.idx[2] = mel_ids;
   ga.table[3] = mel_pos; ga.idx[3] = mel_pos_idx;
   ga.table[4] = extra; ga.idx[4] = extra_idx;
-  return gather_sum_rows(ga, rows, st);
+  ga.table_rows[0] = cfg.number_text_tokens + 1; ga.table_rows[1] = cfg.text_pos_len;
+  ga.table_rows[2] = cfg.number_mel_codes; ga.table_rows[3] = cfg.mel_pos_len;
+  ga.oob = oob_flag;
+  IDX_HIP(hipMemsetAsync(oob_flag, 0, sizeof(int), st));
+  if (gather_sum_rows(ga, rows, st)) return 1;
+  int bad = 0;       // the reference's nn.Embedding raises IndexError on such an id (model_v2.py:759-760); fail as loudly
+  IDX_HIP(hipMemcpyAsync(&bad, oob_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  IDX_HIP(hipStreamSynchronize(st));
+  static const char* names[] = {"", "text token id", "text position", "mel code", "mel position", "conditioning row"};
+  if (bad) IDX_FAIL(std::string("embedding index out of range: ") + names[bad < 6 ? bad : 0]);
+  return 0;
 }
 
 }  // namespace idxtts

@@ -22,6 +22,7 @@ SYMBOLS = [
     "idxtts_profile_enable", "idxtts_profile_num_kernels", "idxtts_profile_kernel_name", "idxtts_profile_read",
     "idxtts_linear_create", "idxtts_linear_fwd", "idxtts_linear_destroy", "idxtts_attention_fwd", "idxtts_attention_bf16x3_fwd", "idxtts_layernorm_fwd",
     "idxtts_gpt_create", "idxtts_gpt_quantize_weights", "idxtts_gpt_workspace_bytes", "idxtts_gpt_embed", "idxtts_gpt_generate", "idxtts_gpt_generate_sampled", "idxtts_gpt_latent",
+    "idxtts_gpt_beam_workspace_bytes", "idxtts_gpt_generate_beam",
     "idxtts_s2mel_create", "idxtts_s2mel_cond_workspace_bytes", "idxtts_s2mel_prepare_cond",
     "idxtts_s2mel_cfm_workspace_bytes", "idxtts_s2mel_cfm", "idxtts_set_gemm_mode", "idxtts_get_gemm_mode",
     "idxtts_s2mel_estimator", "idxtts_cond_create", "idxtts_cond_workspace_bytes", "idxtts_cond_forward", "idxtts_emovec_merge",
@@ -50,6 +51,11 @@ class CondConfigC(ctypes.Structure):         # idxtts_cond_config (include/idxtt
     _fields_ = [(n, c_int) for n in ("input_size", "output_size", "linear_units", "attention_heads", "num_blocks", "cnn_kernel",
                                      "perceiver_dim", "num_latents", "perceiver_depth", "perceiver_dim_head", "perceiver_mult",
                                      "emotion", "model_dim")]
+
+
+class BeamC(ctypes.Structure):               # idxtts_beam (include/idxtts.h)
+    _fields_ = [("num_beams", c_int), ("do_sample", c_int), ("temperature", c_float), ("top_k", c_int), ("top_p", c_float),
+                ("length_penalty", c_float), ("early_stopping", c_int), ("exp_noise", c_void_p)]
 
 
 class S2MelConfigC(ctypes.Structure):
@@ -113,6 +119,10 @@ def load() -> ctypes.CDLL:
                                         c_void_p, c_void_p, c_size_t, c_int, c_void_p]
     lib.idxtts_gpt_generate_sampled.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, POINTER(SamplingC), c_void_p,
                                                 POINTER(c_int), c_void_p, c_void_p, c_size_t, c_int, c_void_p]
+    lib.idxtts_gpt_beam_workspace_bytes.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
+    lib.idxtts_gpt_beam_workspace_bytes.restype = c_size_t
+    lib.idxtts_gpt_generate_beam.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, POINTER(BeamC), c_void_p,
+                                             POINTER(c_int), c_void_p, c_size_t, c_int, c_void_p]
     lib.idxtts_gpt_latent.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.idxtts_s2mel_create.argtypes = [POINTER(S2MelConfigC), POINTER(c_void_p)]
     lib.idxtts_s2mel_cond_workspace_bytes.argtypes = [c_void_p, c_int, c_int, c_int]

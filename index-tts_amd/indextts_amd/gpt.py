@@ -6,9 +6,10 @@
   * forward(...) -> latent                                          model_v2.py:673-723
   * accel_engine-style generate(input_ids, max_new_tokens, ..., attention_mask, tts_embeddings, ...)
                                                                     accel/accel_engine.py:378-645 (plugin slot)
-Difference, by scope: the conformer/perceiver conditioning encoders are not part of
-this hot path, so `speech_conditioning_latent` [B,32,d] and `emo_vec` [B,d] are INPUTS here, where the
-reference derives them from the prompt audio once per prompt (model_v2.py:819-828, 897-910).
+  * get_conditioning / get_emovec / merge_emovec                      model_v2.py:627-671, 897-910 (cond.py, csrc/cond.hip)
+The conformer / perceiver conditioning encoders are built when the state dict carries their weights; `inference_speech`
+then accepts the prompt features [B,T,1024] like the reference does, or -- hoisted out of the segment loop, where the
+reference recomputes them per segment (infer_v2.py:748-765) -- the ready `speech_conditioning_latent` [B,32,d] + `emo_vec`.
 All arithmetic runs in the HIP kernels; numpy/torch only build int32 index arrays and own the buffers.
 """
 from __future__ import annotations
@@ -33,6 +34,8 @@ WEIGHT_FORMATS = {"f32": 0, "bf16": 1, "fp8": 2}
 
 
 class UnifiedVoice:
+    MAX_WORKSPACES = 4
+
     def __init__(self, state_dict, cfg: GPTConfig = GPTConfig(), device="cuda:0", weight_format: str = "f32", keep_effective: bool = False):
         """weight_format: storage of the GPT's linear weights -- "f32" (default), "bf16", or "fp8" (e4m3 + power-of-two scale
         per output channel): the reference's `use_fp16` switch (infer_v2.py:145-146) / BASELINE configs[4].  The weights are
@@ -61,9 +64,13 @@ class UnifiedVoice:
                 if keep_effective:
                     self.effective_state_dict = {k: _lib.get_tensor(ctx, k, tuple(v.shape)) for k, v in sd.items()}
             _lib.load_state_dict(h, sd, before_finalize=hook)
+        from .cond import ConditioningEncoders
+        self.cond = ConditioningEncoders(state_dict, cfg, device=self.device) if ConditioningEncoders.has_weights(state_dict) else None
         se = state_dict["speed_emb.weight"]
         self.speed_emb = (se if isinstance(se, torch.Tensor) else torch.from_numpy(np.asarray(se))).float().to(self.device)
+        import threading
         self._ws = None
+        self._ws_lock = threading.Lock()
         self.stop_mel_token = cfg.stop_mel_token
         self.start_mel_token = cfg.start_mel_token
         self.accel_engine = self       # the reference selects `self.accel_engine.generate` (model_v2.py:871)
@@ -78,23 +85,56 @@ class UnifiedVoice:
         need = int(_lib.load().idxtts_gpt_workspace_bytes(self._h, B, S, max_new))
         if need == 0:
             raise RuntimeError("idxtts_gpt_workspace_bytes returned 0")
-        import threading
+        return self._workspace_bytes(need)
+
+    def _workspace_bytes(self, need: int) -> torch.Tensor:
+        # one workspace per HIP stream (calls on one stream are ordered, so they can share it; generate() may run concurrently
+        # on several streams from several host threads); least-recently-used streams beyond MAX_WORKSPACES are dropped, so
+        # short-lived threads / streams cannot pile up KV arenas
+        import collections
         if self._ws is None:
-            self._ws = {}
-        key = threading.get_ident()                  # one workspace per host thread: generate() may run concurrently on several streams
-        ws = self._ws.get(key)
-        if ws is None or ws.numel() < need:
-            self._ws.pop(key, None)
-            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws = collections.OrderedDict()
+        key = int(torch.cuda.current_stream(self.device).cuda_stream)
+        with self._ws_lock:
+            ws = self._ws.pop(key, None)
+            if ws is None or ws.numel() < need:
+                ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+            while len(self._ws) > self.MAX_WORKSPACES:
+                self._ws.popitem(last=False)
         return ws
 
     def _embed(self, rows: int, text_ids=None, text_pos=None, mel_ids=None, mel_pos=None, extra=None, extra_idx=None):
+        # nn.Embedding raises IndexError on an out-of-range id (the reference's behaviour); the gather kernel would read past
+        # its table instead, so the same check happens here, on the host index arrays, before anything is launched
+        cfg = self.cfg
+        for name, arr, hi in (("text token id", text_ids, cfg.number_text_tokens + 1), ("text position", text_pos, cfg.text_pos_len),
+                              ("mel code", mel_ids, cfg.number_mel_codes), ("mel position", mel_pos, cfg.mel_pos_len),
+                              ("conditioning row", extra_idx, 0 if extra is None else extra.shape[0])):
+            if arr is not None and len(arr) and int(np.max(arr)) >= hi:
+                raise IndexError(f"{name} {int(np.max(arr))} is out of range (table has {hi} rows)")
         out = torch.empty(rows, self.cfg.model_dim, device=self.device, dtype=torch.float32)
         idx = [None if a is None else _i32(self.device, a) for a in (text_ids, text_pos, mel_ids, mel_pos, extra_idx)]
         ex = None if extra is None else extra.to(self.device, torch.float32).contiguous()
         _lib.check(_lib.load().idxtts_gpt_embed(self._h, _lib.ptr(out), rows, _lib.ptr(idx[0]), _lib.ptr(idx[1]), _lib.ptr(idx[2]),
                                                 _lib.ptr(idx[3]), _lib.ptr(ex), _lib.ptr(idx[4]), _lib.current_stream()))
         return out
+
+    # ---- prompt conditioning (model_v2.py:627-671, 897-910): reference names and argument layouts ------------------
+    def _need_cond(self):
+        if self.cond is None:
+            raise RuntimeError("this UnifiedVoice was built without conditioning_encoder / perceiver_encoder weights")
+        return self.cond
+
+    def get_conditioning(self, speech_conditioning_input: torch.Tensor, cond_mel_lengths=None) -> torch.Tensor:
+        """[B,1024,T] (transposed features, as model_v2.py:819 passes them) -> [B,32,d]."""
+        return self._need_cond().get_conditioning(speech_conditioning_input, cond_mel_lengths)
+
+    def get_emovec(self, emo_speech_conditioning_latent: torch.Tensor, emo_cond_lengths=None) -> torch.Tensor:
+        return self._need_cond().get_emovec(emo_speech_conditioning_latent, emo_cond_lengths)
+
+    def merge_emovec(self, speech_conditioning_latent, emo_speech_conditioning_latent, cond_lengths=None, emo_cond_lengths=None, alpha=1.0):
+        return self._need_cond().merge_emovec(speech_conditioning_latent, emo_speech_conditioning_latent, cond_lengths, emo_cond_lengths, alpha)
 
     def conds_latent(self, speech_conditioning_latent: torch.Tensor, emo_vec: torch.Tensor) -> torch.Tensor:
         """cat(latent + emo_vec, speed_emb(1), speed_emb(0)) -> [B, 34, d]   (model_v2.py:830-834)."""
@@ -191,31 +231,101 @@ class UnifiedVoice:
             return out, logits[: n.value].permute(1, 0, 2).contiguous()
         return out
 
-    def inference_speech(self, speech_conditioning_latent, text_inputs, emo_vec=None, max_generate_length=None,
-                         num_return_sequences=1, return_logits=False, **hf_generate_kwargs):
+    def generate_beam(self, input_ids: torch.Tensor, max_new_tokens: int, attention_mask: Optional[torch.Tensor], tts_embeddings: torch.Tensor,
+                      num_beams: int = 3, do_sample: bool = True, temperature: float = 1.0, top_k: int = 50, top_p: float = 1.0,
+                      repetition_penalty: float = 1.0, length_penalty: float = 1.0, early_stopping: bool = False,
+                      exp_noise: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None, use_graph: bool = True) -> torch.Tensor:
+        """HF `generate(num_beams > 1)` of the reference (model_v2.py:885-889 -> transformers_generation_utils.py:3325-3516):
+        beam search, or beam-sample when do_sample.  Returns LongTensor [B, P+1+n]: the best hypothesis per utterance.
+        Sampling draws 2 * num_beams candidates per utterance without replacement: torch.multinomial == top-k of probs / q with
+        q ~ Exp(1) from one exponential_() per step on a [B, num_beams * V] tensor -- `exp_noise` [max_new_tokens, B, num_beams*V]
+        supplies them; when omitted they are drawn on the CPU from `generator` (or the global RNG) in that order."""
+        emb = tts_embeddings.to(self.device, torch.float32).contiguous()
+        B, P, d = emb.shape
+        if input_ids.shape != (B, P + 1):
+            raise ValueError("input_ids must be [B, P+1] (fake prefix + start_mel_token)")
+        if not (2 <= int(num_beams) <= 8) or B * int(num_beams) > 64:
+            raise ValueError("2 <= num_beams <= 8 and B * num_beams <= 64")
+        if early_stopping not in (False, True):
+            raise NotImplementedError('early_stopping="never" is not implemented')
+        pad_left = np.zeros(B, np.int32)
+        if attention_mask is not None:
+            pad_left = (attention_mask.detach().cpu().numpy()[:, :P] == 0).sum(1).astype(np.int32)
+        V, nb = self.cfg.number_mel_codes, int(num_beams)
+        noise = None
+        if do_sample:
+            if exp_noise is None:
+                exp_noise = torch.stack([torch.empty(B, nb * V).exponential_(1, generator=generator) for _ in range(max_new_tokens)])
+            if tuple(exp_noise.shape) != (max_new_tokens, B, nb * V):
+                raise ValueError(f"exp_noise must be [max_new_tokens, B, num_beams * V] = {(max_new_tokens, B, nb * V)}")
+            noise = exp_noise.to(self.device, torch.float32).contiguous()
+        lib = _lib.load()
+        need = int(lib.idxtts_gpt_beam_workspace_bytes(self._h, B, nb, P + 1, max_new_tokens))
+        if need == 0:
+            raise RuntimeError("idxtts_gpt_beam_workspace_bytes returned 0")
+        ws = self._workspace_bytes(need)
+        codes = torch.full((B, max_new_tokens), self.cfg.stop_mel_token, dtype=torch.long, device=self.device)
+        bc = _lib.BeamC(num_beams=nb, do_sample=int(bool(do_sample)), temperature=float(temperature), top_k=int(top_k or 0),
+                        top_p=float(top_p if top_p is not None else 1.0), length_penalty=float(length_penalty),
+                        early_stopping=int(bool(early_stopping)), exp_noise=noise.data_ptr() if noise is not None else None)
+        n = ctypes.c_int(0)
+        _lib.check(lib.idxtts_gpt_generate_beam(self._h, _lib.ptr(emb), pad_left.ctypes.data_as(c_void_p), B, P, max_new_tokens,
+                                                float(repetition_penalty), ctypes.byref(bc), _lib.ptr(codes), ctypes.byref(n), _lib.ptr(ws),
+                                                ws.numel(), int(use_graph), _lib.current_stream()))
+        return torch.cat([input_ids.to(self.device), codes[:, : n.value]], dim=1)
+
+    def inference_speech(self, speech_condition, text_inputs, emo_speech_condition=None, cond_lengths=None, emo_cond_lengths=None,
+                         emo_vec=None, use_speed=False, input_tokens=None, num_return_sequences=1, max_generate_length=None,
+                         typical_sampling=False, typical_mass=.9, return_logits=False, **hf_generate_kwargs):
         """`inference_speech` (model_v2.py:796-895): returns (codes [B, n], speech_conditioning_latent).
-        num_beams=1 only: greedy (do_sample=False) or multinomial sampling with HF's warpers (do_sample=True; extra kwargs
-        `exp_noise` / `generator` / `sampler`, see generate())."""
-        do_sample = bool(hf_generate_kwargs.pop("do_sample", False))
-        if hf_generate_kwargs.pop("num_beams", 1) != 1:
-            raise NotImplementedError("beam search (num_beams > 1) is not implemented on the HIP path (SURVEY §8f rank 2); "
-                                      "greedy and num_beams=1 sampling are")
+        speech_condition: the prompt features [B, T, 1024] as the reference takes them (conditioning encoders run here, model_v2.py:
+        819-828) or -- hoisted out of the caller's segment loop -- the ready conditioning latent [B, 32, d] together with `emo_vec`.
+        Decoding modes = HF generate's: greedy (do_sample=False, num_beams=1), multinomial sampling with the warpers
+        (do_sample=True, num_beams=1; extra kwargs `exp_noise` / `generator` / `sampler`, see generate()), beam search and
+        beam-sample (num_beams > 1: generate_beam())."""
+        if input_tokens is not None or typical_sampling or use_speed:
+            raise NotImplementedError("input_tokens / typical_sampling / use_speed are not used by IndexTTS2.infer and not implemented")
         if num_return_sequences != 1:
             raise NotImplementedError("num_return_sequences must be 1")
+        sc = speech_condition if speech_condition.ndim == 3 else speech_condition.unsqueeze(0)
+        if sc.shape[-1] == self.cfg.cond_module.input_size and sc.shape[-1] != self.cfg.model_dim:      # raw features
+            if emo_speech_condition is None:
+                emo_speech_condition = sc
+            speech_conditioning_latent = self.get_conditioning(sc.transpose(1, 2), cond_lengths)
+            if emo_vec is None:
+                emo_vec = self.get_emovec(emo_speech_condition, emo_cond_lengths)                      # model_v2.py:823-826
+        else:
+            speech_conditioning_latent = sc
+            if emo_vec is None:
+                raise ValueError("pass emo_vec together with a ready conditioning latent")
+        do_sample = bool(hf_generate_kwargs.pop("do_sample", False))
+        num_beams = int(hf_generate_kwargs.pop("num_beams", 1))
         penalty = float(hf_generate_kwargs.pop("repetition_penalty", 1.0))
         samp = {"do_sample": do_sample, "top_p": hf_generate_kwargs.pop("top_p", 1.0), "top_k": hf_generate_kwargs.pop("top_k", 50),
                 "temperature": hf_generate_kwargs.pop("temperature", 1.0), "exp_noise": hf_generate_kwargs.pop("exp_noise", None),
-                "generator": hf_generate_kwargs.pop("generator", None), "sampler": hf_generate_kwargs.pop("sampler", "hf")}
-        hf_generate_kwargs.pop("length_penalty", None)
+                "generator": hf_generate_kwargs.pop("generator", None)}
+        sampler = hf_generate_kwargs.pop("sampler", "hf")
+        length_penalty = float(hf_generate_kwargs.pop("length_penalty", 1.0))
+        early_stopping = hf_generate_kwargs.pop("early_stopping", False)
+        use_graph = bool(hf_generate_kwargs.pop("use_graph", True))
         if hf_generate_kwargs:
             raise TypeError(f"unsupported generate kwargs: {sorted(hf_generate_kwargs)}")
-        conds = self.conds_latent(speech_conditioning_latent, emo_vec)
+        B = text_inputs.shape[0]
+        lat = speech_conditioning_latent.expand(B, -1, -1) if speech_conditioning_latent.shape[0] == 1 else speech_conditioning_latent
+        ev = emo_vec.expand(B, -1) if emo_vec.shape[0] == 1 else emo_vec
+        conds = self.conds_latent(lat, ev)
         input_ids, inputs_embeds, attention_mask = self.prepare_gpt_inputs(conds, text_inputs)
         trunc_index = input_ids.shape[1]
         max_new = (self.cfg.max_mel_tokens - 1) if max_generate_length is None else int(max_generate_length)
+        if num_beams > 1:
+            if return_logits:
+                raise NotImplementedError("return_logits is a num_beams=1 feature")
+            out = self.generate_beam(input_ids, max_new, attention_mask, inputs_embeds, num_beams=num_beams, repetition_penalty=penalty,
+                                     length_penalty=length_penalty, early_stopping=early_stopping, use_graph=use_graph, **samp)
+            return out[:, trunc_index:], speech_conditioning_latent
         out = self.generate(input_ids, max_new_tokens=max_new, stop_tokens=[self.cfg.stop_mel_token],
                             attention_mask=attention_mask, tts_embeddings=inputs_embeds, repetition_penalty=penalty,
-                            return_logits=return_logits, **samp)
+                            return_logits=return_logits, sampler=sampler, use_graph=use_graph, **samp)
         if return_logits:
             return out[0][:, trunc_index:], speech_conditioning_latent, out[1]
         return out[:, trunc_index:], speech_conditioning_latent

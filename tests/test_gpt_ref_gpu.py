@@ -63,3 +63,57 @@ def test_latent_pass_vs_reference(ref, device):
     out = uv.forward(torch.from_numpy(g["cond_latent"]).expand(B, -1, -1), torch.from_numpy(g["latent_text"]), torch.tensor([L, L]),
                      torch.from_numpy(g["latent_codes"]), torch.tensor([M, M]), emo_vec=torch.from_numpy(g["emovec_merged"]).expand(B, -1))
     np.testing.assert_allclose(out.cpu().numpy(), g["latent"], rtol=0, atol=5e-5)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("mode", ["det", "sample"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_beam_search_vs_reference(ref, device, tag, mode, graph):
+    """num_beams=3 -- the mode IndexTTS2.infer runs by default (infer_v2.py:714-722) -- against the reference's inference_speech
+    driven through the vendored beam-search loop and the reference's own BeamSearchScorer (make_gpt_ref): deterministic beams and
+    beam-sample with the stored Exp(1) draws, hypotheses that finish early included (tag b)."""
+    from indextts_amd.gpt import UnifiedVoice
+    g, cfg, w, _ = ref
+    wb = dict(w)
+    wb["mel_head.bias"] = w["mel_head.bias"].copy()
+    wb["mel_head.bias"][cfg.stop_mel_token] += float(g[f"beam_{tag}_stop_bias"])
+    uv = UnifiedVoice(wb, cfg, device=device)
+    noise = torch.from_numpy(g[f"beam_{tag}_noise"])
+    want = g[f"beam_{tag}_{mode}_codes"]
+    codes, _ = uv.inference_speech(torch.from_numpy(g["cond_latent"]), torch.from_numpy(g["text"]), emo_vec=torch.from_numpy(g["emovec_merged"]),
+                                   max_generate_length=noise.shape[0], do_sample=(mode == "sample"), num_beams=3, top_p=0.8, top_k=30,
+                                   temperature=0.8, repetition_penalty=10.0, length_penalty=0.0, exp_noise=noise, use_graph=graph)
+    np.testing.assert_array_equal(codes.cpu().numpy(), want)
+
+
+def test_inference_speech_from_prompt_features_vs_reference(golden_dir, device):
+    """inference_speech fed the raw prompt features, as the reference's call site does (infer_v2.py:760-775): conditioning encoders
+    + emotion vector + greedy decode in one call, equal to the reference's greedy codes."""
+    from indextts_amd import synth
+    from indextts_amd.gpt import UnifiedVoice
+    g = np.load(os.path.join(golden_dir, "gpt_ref.npz"))
+    cfg = GPTConfig.tiny()
+    w = weights.synth_gpt_weights(cfg, tag="golden/gptref")
+    w.update(weights.synth_gpt_cond_weights(cfg, tag="golden/gptref"))
+    uv = UnifiedVoice(w, cfg, device=device)
+    spk = torch.from_numpy(synth.uniform("golden/gptref/spk", (1, 23, 1024), 1.0))
+    emo = torch.from_numpy(synth.uniform("golden/gptref/emo", (1, 19, 1024), 1.0))
+    ln = torch.tensor([1024])
+    emovec = uv.merge_emovec(spk, emo, ln, ln, alpha=0.6)
+    codes, lat = uv.inference_speech(spk, torch.from_numpy(g["text"]), emo, cond_lengths=ln, emo_cond_lengths=ln, emo_vec=emovec,
+                                     max_generate_length=g["speech_greedy_codes"].shape[1], do_sample=False, num_beams=1, repetition_penalty=10.0)
+    np.testing.assert_allclose(lat.cpu().numpy(), g["speech_latent"], rtol=0, atol=1e-4)
+    np.testing.assert_array_equal(codes.cpu().numpy(), g["speech_greedy_codes"])
+
+
+def test_embedding_index_out_of_range_is_rejected(ref, device):
+    """nn.Embedding raises IndexError for an id beyond its table (the reference's behaviour); the HIP gather must not read past it."""
+    g, cfg, w, uv = ref
+    conds = torch.from_numpy(g["conds"]).to(device)
+    bad = torch.from_numpy(g["text"]).clone()
+    bad[0, 3] = cfg.number_text_tokens + 5
+    with pytest.raises(IndexError):
+        uv.prepare_gpt_inputs(conds, bad)
+    long_text = torch.full((1, cfg.max_text_tokens + 1), 5, dtype=torch.long)       # L + 2 > text position table
+    with pytest.raises(IndexError):
+        uv.prepare_gpt_inputs(conds[:1], long_text)
