@@ -185,6 +185,7 @@ typedef struct idxtts_sampling {
   int top_k;             /* 0 = off */
   float top_p;           /* >= 1 = off; < 1 needs 0 < top_k <= 1024 */
   const float* exp_noise;
+  unsigned long long seed;  /* used when exp_noise is NULL: the draws come from a counter-based generator keyed by (seed, step, row, id) */
 } idxtts_sampling;
 int idxtts_gpt_generate_sampled(idxtts_ctx* ctx, const float* inputs_embeds, const int* pad_left, int B, int P, int max_new_tokens,
                                 float repetition_penalty, const idxtts_sampling* sampling, long long* codes, int* n_steps,
@@ -206,6 +207,7 @@ typedef struct idxtts_beam {
   float length_penalty;
   int early_stopping;        /* 0 = False (heuristic, the default), 1 = True */
   const float* exp_noise;
+  unsigned long long seed;   /* used when exp_noise is NULL (see idxtts_sampling) */
 } idxtts_beam;
 size_t idxtts_gpt_beam_workspace_bytes(const idxtts_ctx* ctx, int B, int num_beams, int S, int max_new_tokens);
 int idxtts_gpt_generate_beam(idxtts_ctx* ctx, const float* inputs_embeds, const int* pad_left, int B, int P, int max_new_tokens,

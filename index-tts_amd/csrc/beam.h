@@ -28,7 +28,8 @@ struct BeamState {
   double* hyp_worst = nullptr;        // [B]
   int* done = nullptr;                // [B]
   const DecodeState* st = nullptr;
-  const float* exp_noise = nullptr;   // [steps][B][nb * V] Exp(1) draws (do_sample)
+  const float* exp_noise = nullptr;   // [steps][B][nb * V] Exp(1) draws (do_sample), or null: exp1_draw(seed, ...)
+  unsigned long long seed = 0;
   float* kcache = nullptr; float* vcache = nullptr;   // [L][R][H][16][Smax][4] / [L][R][H][Smax][64]
   int B = 0, nb = 0, V = 0, stop_token = 0, L = 0, H = 0, Smax = 0, prompt_len = 0;   // prompt_len: KV positions shared by all beams (P + 1)
   int do_sample = 0, top_k = 0, early_stopping = 0;

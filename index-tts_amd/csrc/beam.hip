@@ -177,7 +177,7 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(const BeamState p) {
     return;
   }
   const float* base = p.proc + (size_t)b * N;
-  const float* noise = p.do_sample ? p.exp_noise + ((size_t)n * p.B + b) * N : nullptr;
+  const size_t nbase = ((size_t)n * p.B + b) * N;
   float mx = -INFINITY; int mi = 0x7fffffff;
   for (int i = tid; i < N; i += 1024) { const float x = base[i]; if (x > mx || (x == mx && i < mi)) { mx = x; mi = i; } }
   block_argmax1024(mx, mi, rv, ri, tid);
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(const BeamState p) {
       for (int o = 0; o < c; ++o) taken = taken || cand_i[o] == i;
       if (taken) continue;
       const float x = base[i];
-      const float key = p.do_sample ? (expf(x - mx) / tot) / noise[i] : x;
+      const float key = p.do_sample ? (expf(x - mx) / tot) / exp1_draw(p.exp_noise, p.seed, nbase + i) : x;
       if (key > best || (key == best && i < bi)) { best = key; bi = i; }
     }
     block_argmax1024(best, bi, rv, ri, tid);
@@ -267,7 +267,6 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(const BeamState p) {
 
 int beam_select_forward(const BeamState& s, hipStream_t st) {
   IDX_CHECK(s.proc && s.next_tok && s.beam_idx && s.seq && s.hyp_score && s.hyp_len && s.hyp_slot && s.hyp_seq && s.hyp_n && s.hyp_worst && s.st, "null pointer");
-  IDX_CHECK(!s.do_sample || s.exp_noise, "beam-sample needs the Exp(1) draws");
   hipLaunchKernelGGL(beam_select_kernel, dim3(s.B), dim3(1024), 0, st, s);
   IDX_LAUNCH_CHECK();
   return 0;

@@ -50,13 +50,26 @@ int sample_greedy_forward(const SampleArgs& a, hipStream_t stream);
 // mode SAMPLE_ACCEL restates the accel engine's Sampler instead (accel_engine.py:648-659): softmax(logits / T) divided by
 // clamp_min(q, 1e-10), argmax; no penalty, no top-k / top-p.
 enum SampleMode { SAMPLE_HF = 1, SAMPLE_ACCEL = 2 };
+// The Exp(1) draw of element `idx` of a generation: the caller's tensor when it supplied one (reproduces torch's stream), else a
+// counter-based generator -- splitmix64 of (seed, idx) -> u in (0, 1] -> -log(u) -- so that default calls need no
+// [steps][B][V] noise tensor (0.8 GB for 16 utterances x 1500 steps; 2.4 GB with 3 beams).
+__host__ __device__ static inline float exp1_draw(const float* noise, unsigned long long seed, size_t idx) {
+  if (noise) return noise[idx];
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  const float u = ((float)(z >> 40) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
+  return -logf(u);
+}
 struct SampleWarpArgs {
   SampleArgs base;                   // logits source, bookkeeping buffers, penalty (parts must be 1)
   int mode = SAMPLE_HF;
   float temperature = 1.0f;
   int top_k = 0;                     // 0 = off
   float top_p = 1.0f;                // >= 1 = off
-  const float* exp_noise = nullptr;  // [steps][B][V]
+  const float* exp_noise = nullptr;  // [steps][B][V], or null: draws come from exp1_draw(seed, ...)
+  unsigned long long seed = 0;
 };
 int sample_warp_forward(const SampleWarpArgs& a, hipStream_t stream);
 

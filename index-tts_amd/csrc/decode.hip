@@ -344,7 +344,8 @@ __global__ __launch_bounds__(1024) void sample_warp_kernel(const SampleWarpArgs 
   const int V = p.V;
   const unsigned char* seen = p.seen + (size_t)b * V;
   const float* prow = p.part + (size_t)b * V;
-  const float* noise = q.exp_noise + ((size_t)p.st->step * p.B + b) * V;
+  const size_t nbase = ((size_t)p.st->step * p.B + b) * V;
+  auto draw = [&](int v) { return exp1_draw(q.exp_noise, q.seed, nbase + v); };
 
   // ---- scores: logits -> (repetition penalty) -> / temperature ----
   float sc[SW_NPT];
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(1024) void sample_warp_kernel(const SampleWarpArgs 
     for (int u = 0; u < SW_NPT; ++u) {
       const int v = tid + 1024 * u;
       if (v < V) {
-        const float r = (expf(sc[u] - mx) / tot) / fmaxf(noise[v], qmin);
+        const float r = (expf(sc[u] - mx) / tot) / fmaxf(draw(v), qmin);
         if (r > best) { best = r; bi = v; }
       }
     }
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(1024) void sample_warp_kernel(const SampleWarpArgs 
     float best = -INFINITY; int bi = 0x7fffffff;
     for (int e = s_keep_from + tid; e < n; e += 1024) {
       const int v = sorted_i[e];
-      const float r = (expf(sorted_v[e] - mx) / s_sum) / noise[v];
+      const float r = (expf(sorted_v[e] - mx) / s_sum) / draw(v);
       if (r > best || (r == best && v < bi)) { best = r; bi = v; }
     }
     block_argmax(best, bi, rv, ri, tid);
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(1024) void sample_warp_kernel(const SampleWarpArgs 
 
 int sample_warp_forward(const SampleWarpArgs& a, hipStream_t stream) {
   const SampleArgs& b = a.base;
-  IDX_CHECK(b.part && b.parts == 1 && b.seen && b.finished && b.codes && b.cur_tok && b.st && a.exp_noise, "null pointer");
+  IDX_CHECK(b.part && b.parts == 1 && b.seen && b.finished && b.codes && b.cur_tok && b.st, "null pointer");
   IDX_CHECK(b.V > 0 && b.V <= 1024 * SW_NPT, "vocabulary size");
   IDX_CHECK(a.temperature > 0.0f && a.top_k >= 0 && a.top_p > 0.0f, "sampling parameters");
   IDX_CHECK(a.mode == SAMPLE_HF || a.mode == SAMPLE_ACCEL, "sampling mode");

@@ -296,7 +296,7 @@ int GPTModel::layer_full(int li, const Buffers& w, int B, int S, const int* ksta
 }
 
 // sampling mode of the generation this host thread is running (mode 0 = greedy)
-static thread_local idxtts_sampling samp{0, 1.0f, 0, 1.0f, nullptr};
+static thread_local idxtts_sampling samp{0, 1.0f, 0, 1.0f, nullptr, 0};
 thread_local const BeamState* tl_beam = nullptr;
 
 // head on B rows: ln_f -> final_norm (one rows_norm launch, output as fragment images) -> mel_head -> greedy sampler
@@ -318,7 +318,7 @@ int GPTModel::head_and_sample(const Buffers& w, int B, const float* x, int ldx, 
   if (samp.mode != 0) {
     SampleWarpArgs sw;
     sw.base = s; sw.mode = samp.mode; sw.temperature = samp.temperature; sw.top_k = samp.top_k; sw.top_p = samp.top_p;
-    sw.exp_noise = samp.exp_noise;
+    sw.exp_noise = samp.exp_noise; sw.seed = samp.seed;
     return sample_warp_forward(sw, st);
   }
   return sample_greedy_forward(s, st);
@@ -383,10 +383,10 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
     st = own_stream;
   }
   IDX_CHECK(B > 0 && B <= 64 && P > 0 && max_new > 0, "shape (1 <= B <= 64)");
-  samp = idxtts_sampling{0, 1.0f, 0, 1.0f, nullptr};
+  samp = idxtts_sampling{0, 1.0f, 0, 1.0f, nullptr, 0};
   if (sampling && sampling->mode != 0) {
     IDX_CHECK(sampling->mode == SAMPLE_HF || sampling->mode == SAMPLE_ACCEL, "sampling mode");
-    IDX_CHECK(sampling->exp_noise && sampling->temperature > 0.0f, "sampling needs the Exp(1) draws and a positive temperature");
+    IDX_CHECK(sampling->temperature > 0.0f, "sampling needs a positive temperature");
     IDX_CHECK(sampling->top_p >= 1.0f || (sampling->top_k > 0 && sampling->top_k <= 1024), "top-p needs 0 < top_k <= 1024");
     samp = *sampling;
   }

@@ -71,8 +71,8 @@ int GPTModel::generate_beam(const float* inputs_embeds, const int* pad_left_host
   const int nb = beam->num_beams, R = B * nb;
   IDX_CHECK(nb >= 2 && nb <= BEAM_MAX, "2 <= num_beams <= 8");
   IDX_CHECK(B > 0 && R <= 64 && P > 0 && max_new > 0, "shape (B * num_beams <= 64)");
-  IDX_CHECK(!beam->do_sample || (beam->exp_noise && beam->temperature > 0.0f && beam->top_k >= 0 && beam->top_k <= 1024 && beam->top_p > 0.0f),
-            "beam-sample needs the Exp(1) draws, a positive temperature, top_k <= 1024 and top_p > 0");
+  IDX_CHECK(!beam->do_sample || (beam->temperature > 0.0f && beam->top_k >= 0 && beam->top_k <= 1024 && beam->top_p > 0.0f),
+            "beam-sample needs a positive temperature, top_k <= 1024 and top_p > 0");
   IDX_CHECK(beam->early_stopping == 0 || beam->early_stopping == 1, "early_stopping must be 0 (False) or 1 (True)");
   const int d = cfg.model_dim, V = cfg.number_mel_codes, S = P + 1;
   IDX_CHECK(max_new + 1 < cfg.mel_pos_len, "max_new_tokens exceeds the mel position table");
@@ -113,7 +113,7 @@ int GPTModel::generate_beam(const float* inputs_embeds, const int* pad_left_host
   bst.logits = w.logits; bst.proc = bb.proc; bst.seen = w.seen; bst.beam_scores = bb.beam_scores; bst.next_tok = bb.next_tok;
   bst.beam_idx = bb.beam_idx; bst.seq = bb.seq; bst.seq_ld = max_new; bst.cur_tok = w.cur_tok;
   bst.hyp_score = bb.hyp_score; bst.hyp_len = bb.hyp_len; bst.hyp_slot = bb.hyp_slot; bst.hyp_seq = bb.hyp_seq; bst.hyp_n = bb.hyp_n;
-  bst.hyp_worst = bb.hyp_worst; bst.done = bb.done; bst.st = w.state; bst.exp_noise = beam->exp_noise;
+  bst.hyp_worst = bb.hyp_worst; bst.done = bb.done; bst.st = w.state; bst.exp_noise = beam->exp_noise; bst.seed = beam->seed;
   bst.kcache = w.kcache; bst.vcache = w.vcache;
   bst.B = B; bst.nb = nb; bst.V = V; bst.stop_token = cfg.stop_mel_token; bst.L = cfg.layers; bst.H = cfg.heads; bst.Smax = w.Smax;
   bst.prompt_len = S;

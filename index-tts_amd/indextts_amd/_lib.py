@@ -44,7 +44,8 @@ class GPTConfigC(ctypes.Structure):
 
 
 class SamplingC(ctypes.Structure):          # idxtts_sampling (include/idxtts.h)
-    _fields_ = [("mode", c_int), ("temperature", c_float), ("top_k", c_int), ("top_p", c_float), ("exp_noise", c_void_p)]
+    _fields_ = [("mode", c_int), ("temperature", c_float), ("top_k", c_int), ("top_p", c_float), ("exp_noise", c_void_p),
+                ("seed", ctypes.c_ulonglong)]
 
 
 class CondConfigC(ctypes.Structure):         # idxtts_cond_config (include/idxtts.h)
@@ -55,7 +56,7 @@ class CondConfigC(ctypes.Structure):         # idxtts_cond_config (include/idxtt
 
 class BeamC(ctypes.Structure):               # idxtts_beam (include/idxtts.h)
     _fields_ = [("num_beams", c_int), ("do_sample", c_int), ("temperature", c_float), ("top_k", c_int), ("top_p", c_float),
-                ("length_penalty", c_float), ("early_stopping", c_int), ("exp_noise", c_void_p)]
+                ("length_penalty", c_float), ("early_stopping", c_int), ("exp_noise", c_void_p), ("seed", ctypes.c_ulonglong)]
 
 
 class S2MelConfigC(ctypes.Structure):

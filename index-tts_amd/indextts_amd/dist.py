@@ -43,20 +43,33 @@ def broadcast_conditioning(cond: Optional[PromptConditioning], shapes, device, s
     return PromptConditioning.unpack(flat, shapes)
 
 
-def gather_waveforms(wavs: List[torch.Tensor], dst: int = 0) -> Optional[List[List[torch.Tensor]]]:
-    """wavs: this rank's list of [1, n_i] waveforms (same count on every rank).  Returns, on rank `dst`,
-    a list over ranks of lists of waveforms trimmed to their true lengths; None elsewhere."""
+def gather_waveforms(wavs: List[torch.Tensor], dst: int = 0, device=None, same_count: bool = False) -> Optional[List[List[torch.Tensor]]]:
+    """wavs: this rank's list of [1, n_i] waveforms -- the count may differ between ranks (`shard_bounds` hands out uneven
+    shards) and may be zero (then pass `device`).  Returns, on rank `dst`, a list over ranks of lists of waveforms trimmed to
+    their true lengths; None elsewhere.  Three one-shot collectives: all_gather of the counts, all_gather of the sample
+    counts (padded to the largest shard), gather of the padded waveforms; `same_count=True` (every rank holds len(wavs)
+    utterances, e.g. fixed batches) skips the first."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    dev = wavs[0].device
-    lens = torch.tensor([w.shape[-1] for w in wavs], device=dev, dtype=torch.int64)
+    dev = wavs[0].device if wavs else torch.device(device if device is not None else "cpu")
+    if same_count:
+        counts = [len(wavs)] * world
+    else:
+        count = torch.tensor([len(wavs)], device=dev, dtype=torch.int64)
+        counts = [torch.empty_like(count) for _ in range(world)]
+        dist.all_gather(counts, count)
+        counts = [int(c.item()) for c in counts]
+    cmax = max(counts)
+    if cmax == 0:
+        return [[] for _ in range(world)] if rank == dst else None
+    lens = torch.tensor([w.shape[-1] for w in wavs] + [0] * (cmax - len(wavs)), dtype=torch.int64).to(dev)
     all_lens = [torch.empty_like(lens) for _ in range(world)]
     dist.all_gather(all_lens, lens)
-    nmax = int(max(int(l.max()) for l in all_lens))
-    padded = torch.zeros(len(wavs), nmax, device=dev, dtype=torch.float32)
+    nmax = max(1, int(max(int(l.max()) for l in all_lens)))
+    padded = torch.zeros(cmax, nmax, device=dev, dtype=torch.float32)
     for i, w in enumerate(wavs):
         padded[i, : w.shape[-1]] = w.reshape(-1)
     out = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
     dist.gather(padded, out, dst=dst)
     if rank != dst:
         return None
-    return [[out[r][i, : int(all_lens[r][i])].unsqueeze(0) for i in range(len(wavs))] for r in range(world)]
+    return [[out[r][i, : int(all_lens[r][i])].unsqueeze(0) for i in range(counts[r])] for r in range(world)]

@@ -187,8 +187,8 @@ class UnifiedVoice:
         sampler="hf" = HF `_sample` with its warpers (repetition penalty -> temperature -> top-k -> top-p -> multinomial,
         transformers_generation_utils.py:1036-1044, 3222-3250), sampler="accel" = the accel engine's own Sampler
         (softmax(logits / T) / Exp(1) noise, argmax; accel_engine.py:648-659).  torch.multinomial(probs, 1) is
-        argmax(probs / q) with q ~ Exp(1): `exp_noise` [max_new_tokens, B, V] supplies the draws; when omitted they are
-        drawn on the CPU from `generator` (or the global RNG) with one exponential_() per step, the order HF consumes them."""
+        argmax(probs / q) with q ~ Exp(1): `exp_noise` [max_new_tokens, B, V] supplies the draws, or `generator` draws them on the
+        CPU with one exponential_() per step, the order HF consumes them; with neither the kernels generate them (see _noise)."""
         if tts_embeddings is None:
             raise ValueError("tts_embeddings ([pad][cond][text] prompt embeddings) is required")
         if stop_tokens is not None and list(stop_tokens) != [self.cfg.stop_mel_token]:
@@ -209,15 +209,11 @@ class UnifiedVoice:
         if do_sample:
             if sampler not in ("hf", "accel"):
                 raise ValueError("sampler must be 'hf' or 'accel'")
-            if exp_noise is None:
-                exp_noise = torch.stack([torch.empty(B, V).exponential_(1, generator=generator) for _ in range(max_new_tokens)])
-            if tuple(exp_noise.shape) != (max_new_tokens, B, V):
-                raise ValueError(f"exp_noise must be [max_new_tokens, B, V] = {(max_new_tokens, B, V)}")
-            noise = exp_noise.to(self.device, torch.float32).contiguous()
+            noise, seed = self._noise(exp_noise, generator, (max_new_tokens, B, V))
             sc = _lib.SamplingC(mode=1 if sampler == "hf" else 2, temperature=float(temperature),
                                 top_k=int(top_k or 0) if sampler == "hf" else 0,
                                 top_p=float(top_p if top_p is not None else 1.0) if sampler == "hf" else 1.0,
-                                exp_noise=noise.data_ptr())
+                                exp_noise=noise.data_ptr() if noise is not None else None, seed=seed)
             _lib.check(_lib.load().idxtts_gpt_generate_sampled(
                 self._h, _lib.ptr(emb), pad_left.ctypes.data_as(c_void_p), B, P, max_new_tokens, float(repetition_penalty),
                 ctypes.byref(sc), _lib.ptr(codes), ctypes.byref(n), _lib.ptr(logits), _lib.ptr(ws), ws.numel(), int(use_graph),
@@ -231,6 +227,19 @@ class UnifiedVoice:
             return out, logits[: n.value].permute(1, 0, 2).contiguous()
         return out
 
+    def _noise(self, exp_noise, generator, shape):
+        """The Exp(1) draws of a sampled generation: (device tensor | None, seed).  An explicit `exp_noise`, or a torch `generator`
+        (one exponential_() per step, the order HF consumes them: reproduces the reference's stream under that seed); with neither,
+        the kernels draw from a counter-based generator keyed by a 63-bit seed taken from torch's global RNG (so torch.manual_seed
+        still makes a run repeatable) -- no [steps, B, V] tensor is materialised."""
+        if exp_noise is None and generator is None:
+            return None, int(torch.randint(0, 2 ** 62, (1,)).item())
+        if exp_noise is None:
+            exp_noise = torch.stack([torch.empty(shape[1:]).exponential_(1, generator=generator) for _ in range(shape[0])])
+        if tuple(exp_noise.shape) != tuple(shape):
+            raise ValueError(f"exp_noise must be {tuple(shape)}")
+        return exp_noise.to(self.device, torch.float32).contiguous(), 0
+
     def generate_beam(self, input_ids: torch.Tensor, max_new_tokens: int, attention_mask: Optional[torch.Tensor], tts_embeddings: torch.Tensor,
                       num_beams: int = 3, do_sample: bool = True, temperature: float = 1.0, top_k: int = 50, top_p: float = 1.0,
                       repetition_penalty: float = 1.0, length_penalty: float = 1.0, early_stopping: bool = False,
@@ -239,7 +248,7 @@ class UnifiedVoice:
         beam search, or beam-sample when do_sample.  Returns LongTensor [B, P+1+n]: the best hypothesis per utterance.
         Sampling draws 2 * num_beams candidates per utterance without replacement: torch.multinomial == top-k of probs / q with
         q ~ Exp(1) from one exponential_() per step on a [B, num_beams * V] tensor -- `exp_noise` [max_new_tokens, B, num_beams*V]
-        supplies them; when omitted they are drawn on the CPU from `generator` (or the global RNG) in that order."""
+        supplies them, or `generator` draws them on the CPU in that order; with neither the kernels generate them (see _noise)."""
         emb = tts_embeddings.to(self.device, torch.float32).contiguous()
         B, P, d = emb.shape
         if input_ids.shape != (B, P + 1):
@@ -252,13 +261,7 @@ class UnifiedVoice:
         if attention_mask is not None:
             pad_left = (attention_mask.detach().cpu().numpy()[:, :P] == 0).sum(1).astype(np.int32)
         V, nb = self.cfg.number_mel_codes, int(num_beams)
-        noise = None
-        if do_sample:
-            if exp_noise is None:
-                exp_noise = torch.stack([torch.empty(B, nb * V).exponential_(1, generator=generator) for _ in range(max_new_tokens)])
-            if tuple(exp_noise.shape) != (max_new_tokens, B, nb * V):
-                raise ValueError(f"exp_noise must be [max_new_tokens, B, num_beams * V] = {(max_new_tokens, B, nb * V)}")
-            noise = exp_noise.to(self.device, torch.float32).contiguous()
+        noise, seed = self._noise(exp_noise, generator, (max_new_tokens, B, nb * V)) if do_sample else (None, 0)
         lib = _lib.load()
         need = int(lib.idxtts_gpt_beam_workspace_bytes(self._h, B, nb, P + 1, max_new_tokens))
         if need == 0:
@@ -267,7 +270,7 @@ class UnifiedVoice:
         codes = torch.full((B, max_new_tokens), self.cfg.stop_mel_token, dtype=torch.long, device=self.device)
         bc = _lib.BeamC(num_beams=nb, do_sample=int(bool(do_sample)), temperature=float(temperature), top_k=int(top_k or 0),
                         top_p=float(top_p if top_p is not None else 1.0), length_penalty=float(length_penalty),
-                        early_stopping=int(bool(early_stopping)), exp_noise=noise.data_ptr() if noise is not None else None)
+                        early_stopping=int(bool(early_stopping)), exp_noise=noise.data_ptr() if noise is not None else None, seed=seed)
         n = ctypes.c_int(0)
         _lib.check(lib.idxtts_gpt_generate_beam(self._h, _lib.ptr(emb), pad_left.ctypes.data_as(c_void_p), B, P, max_new_tokens,
                                                 float(repetition_penalty), ctypes.byref(bc), _lib.ptr(codes), ctypes.byref(n), _lib.ptr(ws),

@@ -1,9 +1,11 @@
 """Host-side mirror of `indextts.infer_v2.IndexTTS2` for the hot path (reference infer_v2.py:69-937).
 
-Scope: the three hot stages -- GPT decode + latent pass, s2mel, BigVGAN -- and the segment loop
-that sequences them (infer_v2.py:732-881), with the reference's return contract (905-937).  The prompt-side
-encoders (w2v-bert, RepCodec, CAMPPlus, conformer/perceiver; infer_v2.py:618-696, model_v2.py:627-671) and the
-text front-end are "next" rows (§8f): their OUTPUTS enter here as a `PromptConditioning` bundle and token ids.
+Scope: the three hot stages -- GPT decode + latent pass, s2mel, BigVGAN -- the GPT's own prompt
+conditioning (conformer + perceiver + emotion vector, model_v2.py:627-671, 897-910; hoisted out of the segment loop) and the
+segment loop that sequences them (infer_v2.py:732-881), with the reference's return contract (905-937) and generation
+defaults (714-722: beam-sample, num_beams=3).  The audio-side prompt encoders (w2v-bert, RepCodec, CAMPPlus, mel; infer_v2.py:
+618-696) and the text front-end are "next" rows (§8f): their OUTPUTS enter here as prompt features (`PromptFeatures`) or a ready
+`PromptConditioning` bundle, and token ids.
 """
 from __future__ import annotations
 
@@ -33,6 +35,26 @@ class InferenceResult:                       # infer_v2.py:58-66
 
 
 @dataclass
+class PromptFeatures:
+    """What the reference's audio-side prompt encoders leave behind per prompt (infer_v2.py:637-658, 691-694): the inputs of the
+    GPT's conditioning encoders plus the s2mel conditioning."""
+    spk_cond_emb: torch.Tensor        # [1, T50, 1024]  w2v-bert layer-17 features of the speaker prompt     infer_v2.py:637
+    style: torch.Tensor               # [1, 192]        CAMPPlus                                              infer_v2.py:647
+    prompt_condition: torch.Tensor    # [1, Tp, 512]    length_regulator(S_ref)                               infer_v2.py:649
+    ref_mel: torch.Tensor             # [1, 80, Tp]     mel_fn(prompt audio)                                  infer_v2.py:640
+    emo_cond_emb: Optional[torch.Tensor] = None       # [1, T50', 1024] features of the emotion prompt (default: the speaker's, 583-584)
+
+    @staticmethod
+    def synthetic(cfg: PipelineConfig, prompt_frames: int = 689, feat_frames: int = 400, tag: str = "prompt", emo_frames: int = 0) -> "PromptFeatures":
+        """Seeded stand-in for an 8 s prompt (spk_cond_emb [1,400,1024], Tp = 689)."""
+        t = lambda n, shape, s, o=0.0: torch.from_numpy(synth.uniform(f"{tag}/{n}", shape, s, o))
+        return PromptFeatures(t("spk_cond_emb", (1, feat_frames, cfg.gpt.cond_module.input_size), 1.0), t("style", (1, cfg.s2mel.style_dim), 1.0),
+                              t("prompt_condition", (1, prompt_frames, cfg.s2mel.content_dim), 1.0),
+                              t("ref_mel", (1, cfg.s2mel.in_channels, prompt_frames), 2.6, -4.0),
+                              t("emo_cond_emb", (1, emo_frames, cfg.gpt.cond_module.input_size), 1.0) if emo_frames else None)
+
+
+@dataclass
 class PromptConditioning:
     """What the reference caches per prompt (infer_v2.py:654-658, 693-694) after its encoders have run."""
     spk_cond_latent: torch.Tensor     # [1, 32, d]   get_conditioning(spk_cond_emb)           model_v2.py:819
@@ -52,6 +74,20 @@ class PromptConditioning:
             t("latent", (1, cfg.gpt.cond_latents, d), 0.5), t("emo", (1, d), 0.3), t("style", (1, cfg.s2mel.style_dim), 1.0),
             t("prompt_condition", (1, prompt_frames, cfg.s2mel.content_dim), 1.0),
             t("ref_mel", (1, cfg.s2mel.in_channels, prompt_frames), 2.6, -4.0))
+
+    @staticmethod
+    def from_features(gpt: UnifiedVoice, feats: "PromptFeatures", emo_alpha: float = 1.0) -> "PromptConditioning":
+        """The per-prompt half of the reference's segment loop, once per prompt instead of once per segment:
+        `merge_emovec(spk_cond_emb, emo_cond_emb, ..., alpha=emo_alpha)` (infer_v2.py:748-754) and the `get_conditioning` call
+        inside `inference_speech` (model_v2.py:819), on the HIP conditioning encoders.  The "lengths" are the reference's:
+        `shape[-1]` of the [1,T,1024] tensors (infer_v2.py:751-752), i.e. no padding."""
+        dev = gpt.device
+        spk = feats.spk_cond_emb.to(dev, torch.float32)
+        emo = spk if feats.emo_cond_emb is None else feats.emo_cond_emb.to(dev, torch.float32)
+        ln_s, ln_e = torch.tensor([spk.shape[-1]]), torch.tensor([emo.shape[-1]])
+        emovec = gpt.merge_emovec(spk, emo, ln_s, ln_e, alpha=emo_alpha)
+        latent = gpt.get_conditioning(spk.transpose(1, 2), ln_s)
+        return PromptConditioning(latent, emovec, feats.style, feats.prompt_condition, feats.ref_mel)
 
     def to(self, device) -> "PromptConditioning":
         return PromptConditioning(*[getattr(self, f).to(device, torch.float32).contiguous() for f in self.FIELDS])
@@ -156,9 +192,10 @@ class IndexTTS2:
         t0 = self._tick(sync_timers)
         lat = c.spk_cond_latent.expand(B, -1, -1) if c.spk_cond_latent.shape[0] == 1 else c.spk_cond_latent
         emo = c.emo_vec.expand(B, -1) if c.emo_vec.shape[0] == 1 else c.emo_vec
+        gen = dict(sampling) if sampling else {"do_sample": False}
+        gen.setdefault("num_beams", 1)
         codes, _ = self.gpt.inference_speech(lat, text_tokens, emo_vec=emo, max_generate_length=max_mel_tokens,
-                                             repetition_penalty=repetition_penalty, num_beams=1,
-                                             **(sampling if sampling else {"do_sample": False}))
+                                             repetition_penalty=repetition_penalty, **gen)
         t1 = self._tick(sync_timers)
         times["gpt_gen_time"] = t1 - t0
         # trim at the first stop token (infer_v2.py:795-807)
@@ -255,32 +292,56 @@ class IndexTTS2:
         CPU, already scaled and clamped to +-32767) and then the inter-segment silence, and nothing else (874-879, 885-886)."""
         if stream_return and return_audio:
             raise ValueError("stream_return and return_audio are mutually exclusive")                # infer_v2.py:575-576
-        if not isinstance(spk_audio_prompt, PromptConditioning):
-            raise NotImplementedError("prompt encoders (w2v-bert / RepCodec / CAMPPlus / conformer-perceiver) are outside this "
-                                      "hot path (SURVEY.md §8f rank 1): pass a PromptConditioning")
         if isinstance(text, str):
             raise NotImplementedError("the text front-end (tokenizer/segmenter) is outside this hot path (SURVEY.md §8f rank 3): "
                                       "pass token ids")
-        if emo_audio_prompt is not None or emo_vector is not None or use_emo_text:
-            raise NotImplementedError("emotion routing happens upstream: fold it into PromptConditioning.emo_vec")
+        if emo_vector is not None or use_emo_text:
+            raise NotImplementedError("emo_vector / emo_text routing (emotion matrices, Qwen classifier: infer_v2.py:586-615, 668-679) "
+                                      "happens upstream of this path: fold the result into PromptConditioning.emo_vec")
+        if isinstance(spk_audio_prompt, PromptFeatures):
+            # prompt-feature path: conformer + perceiver + emotion vector on the GPU, cached per (prompt, emotion prompt, alpha) like
+            # the reference caches its prompt features (infer_v2.py:618, 681)
+            feats = spk_audio_prompt
+            if emo_audio_prompt is not None:
+                if not isinstance(emo_audio_prompt, (PromptFeatures, torch.Tensor)):
+                    raise NotImplementedError("emo_audio_prompt must be a PromptFeatures or the emotion prompt's [1,T,1024] features")
+                emo_emb = emo_audio_prompt.spk_cond_emb if isinstance(emo_audio_prompt, PromptFeatures) else emo_audio_prompt
+                feats = PromptFeatures(feats.spk_cond_emb, feats.style, feats.prompt_condition, feats.ref_mel, emo_emb)
+            key = (id(spk_audio_prompt), id(emo_audio_prompt), float(emo_alpha))
+            if getattr(self, "_cond_cache_key", None) != key:
+                self._cond_cache = PromptConditioning.from_features(self.gpt, feats, emo_alpha=emo_alpha)
+                self._cond_cache_key = key
+                self._cond_cache_refs = (spk_audio_prompt, emo_audio_prompt)     # keep the ids alive
+            spk_audio_prompt = self._cond_cache
+        elif emo_audio_prompt is not None:
+            raise NotImplementedError("with a ready PromptConditioning the emotion prompt is already folded into emo_vec")
+        if not isinstance(spk_audio_prompt, PromptConditioning):
+            raise NotImplementedError("audio-side prompt encoders (w2v-bert / RepCodec / CAMPPlus / mel) are outside this hot path "
+                                      "(SURVEY.md §8f rank 1): pass PromptFeatures or a PromptConditioning")
         segs = text if (len(text) and isinstance(text[0], (list, tuple, np.ndarray, torch.Tensor))) else [text]
         segs = [torch.as_tensor(s, dtype=torch.long).reshape(1, -1) for s in segs]
         if not segs or any(s.numel() == 0 for s in segs):
             return                                                                                   # nothing yielded -> infer() returns None
-        do_sample = generation_kwargs.pop("do_sample", False)
-        num_beams = generation_kwargs.pop("num_beams", 1)
-        if num_beams != 1:
-            raise NotImplementedError("beam search is not implemented on the HIP path (SURVEY.md §8f rank 2): pass num_beams=1 "
-                                      "(greedy, or do_sample=True for multinomial sampling with top_k / top_p / temperature)")
+        # generation kwargs and their defaults: infer_v2.py:714-722.  The reference pops `do_sample` and then hard-codes
+        # do_sample=True in the call (line 767): its default mode is beam-sample with 3 beams.  Here the popped value is honoured
+        # (do_sample=False, num_beams=1 is the greedy parity mode of BASELINE configs[2]); the defaults are the reference's.
+        do_sample = generation_kwargs.pop("do_sample", True)
+        top_p = generation_kwargs.pop("top_p", 0.8)
+        top_k = generation_kwargs.pop("top_k", 30)
+        temperature = generation_kwargs.pop("temperature", 0.8)
+        length_penalty = generation_kwargs.pop("length_penalty", 0.0)
+        num_beams = generation_kwargs.pop("num_beams", 3)
         repetition_penalty = generation_kwargs.pop("repetition_penalty", 10.0)
         max_mel_tokens = generation_kwargs.pop("max_mel_tokens", 1500)
-        sampling = None
-        if do_sample:      # reference defaults: top_p 0.8, top_k 30, temperature 0.8 (infer_v2.py:715-717)
-            sampling = {"do_sample": True, "top_p": generation_kwargs.pop("top_p", 0.8), "top_k": generation_kwargs.pop("top_k", 30),
-                        "temperature": generation_kwargs.pop("temperature", 0.8), "sampler": generation_kwargs.pop("sampler", "hf"),
-                        "generator": generation_kwargs.pop("generator", None)}
-        for k in ("top_p", "top_k", "temperature", "length_penalty"):
-            generation_kwargs.pop(k, None)
+        sampling = {"do_sample": bool(do_sample), "num_beams": int(num_beams), "generator": generation_kwargs.pop("generator", None)}
+        if do_sample:
+            sampling.update(top_p=top_p, top_k=top_k, temperature=temperature)
+        if num_beams > 1:
+            sampling["length_penalty"] = length_penalty
+        elif do_sample:
+            sampling["sampler"] = generation_kwargs.pop("sampler", "hf")
+        if generation_kwargs:
+            raise TypeError(f"unsupported generation kwargs: {sorted(generation_kwargs)}")
         start = time.perf_counter()
         wavs = []
         sil = self.interval_silence(interval_silence=interval_silence)

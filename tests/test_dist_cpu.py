@@ -39,6 +39,16 @@ def _worker(rank, world, port, q):
                 ok = ok and w.shape == (1, 10 + 3 * i + r) and bool((w == 100 * r + i).all())
     else:
         ok = ok and res is None
+    # uneven shards: 5 utterances over 2 ranks (3 + 2), then 1 over 2 (1 + 0: an empty shard)
+    for total in (5, 1):
+        lo2, hi2 = shard_bounds(total, world, rank)
+        mine = [torch.full((1, 7 + i), float(i)) for i in range(lo2, hi2)]
+        res = gather_waveforms(mine, dst=0, device="cpu")
+        if rank == 0:
+            flat = [w for r in range(world) for w in res[r]]
+            ok = ok and len(flat) == total and all(w.shape == (1, 7 + i) and bool((w == i).all()) for i, w in enumerate(flat))
+        else:
+            ok = ok and res is None
     q.put((rank, ok, (lo, hi)))
     dist.destroy_process_group()
 
@@ -74,3 +84,18 @@ def test_conditioning_pack_roundtrip():
     c = PromptConditioning.synthetic(PipelineConfig.tiny(), prompt_frames=9)
     r = PromptConditioning.unpack(c.pack(), c.shapes())
     assert all(torch.equal(getattr(c, f), getattr(r, f)) for f in PromptConditioning.FIELDS)
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` starts N ranks under torch.distributed.run on 127.0.0.1, the command shape the driver uses,
+    and forwards its own flags unchanged."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.launcher_command(["--gpus", "8", "--steps", "5", "--warmup", "1"], 8, 29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=8" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "1"]
