@@ -1,0 +1,139 @@
+"""GPU, FULL-SIZE weights, at BASELINE.json's own sizes:
+  configs[4]  long-form: one utterance, 1500 codes (30 s), emotion vector mixed in, fp8 GPT weight streams, graph-replayed decode
+  configs[2]  batch 16 x 512 codes, greedy
+The CPU oracle cannot run these end to end in test time, so: graph replay == eager launch for all 1500 steps (bit for bit),
+the first codes and one estimator evaluation at the full T = 689 + 2580 against the oracle, the vocoder at 2580 frames
+against the oracle on an interior window (locality), and batch rows == their own B = 1 runs."""
+import numpy as np
+import pytest
+import torch
+
+from indextts_amd import synth, weights
+from indextts_amd.config import PipelineConfig
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full(device):
+    cfg = PipelineConfig()
+    wg = weights.synth_gpt_weights(cfg.gpt, tag="bench/gpt")
+    wg["mel_head.bias"] = wg["mel_head.bias"].copy()
+    wg["mel_head.bias"][cfg.gpt.stop_mel_token] = -1e4         # fixed-length synthetic utterances (as bench.py)
+    ws = weights.synth_s2mel_weights(cfg.s2mel, tag="bench/s2mel")
+    wv = weights.synth_bigvgan_weights(cfg.bigvgan, tag="bench/bigvgan")
+    return cfg, wg, ws, wv
+
+
+def _cond(cfg, emo_scale=0.3):
+    from indextts_amd.infer_v2 import PromptConditioning
+    c = PromptConditioning.synthetic(cfg, prompt_frames=689, tag="bench/prompt")
+    return c
+
+
+def test_config4_longform_decode_graph_equals_eager_and_oracle(device, full):
+    """1500 steps at B = 1 on fp8 weight streams: the hipGraph replay and the eager launches produce the same 1500 codes, and the
+    first 24 equal the CPU oracle running the SAME rounded model (idxtts_ctx_get_tensor hands it back)."""
+    from indextts_amd.gpt import UnifiedVoice
+    from oracle import gpt as og
+    cfg, wg, ws, wv = full
+    uv = UnifiedVoice(wg, cfg.gpt, device=device, weight_format="fp8", keep_effective=True)
+    c = _cond(cfg)
+    emo2 = torch.from_numpy(synth.uniform("t/full/emo2", (1, cfg.gpt.model_dim), 0.3))
+    emo = c.emo_vec + 1.0 * (emo2 - c.emo_vec)                  # merge_emovec's mix, alpha = 1.0 (configs[4]: emotion-prompted)
+    text = torch.from_numpy(synth.integers("t/full/text4", (1, 128), 2, cfg.gpt.number_text_tokens))
+    M = 1500
+    runs = {}
+    for graph in (True, False):
+        codes, _ = uv.inference_speech(c.spk_cond_latent, text, emo_vec=emo, max_generate_length=M, do_sample=False, num_beams=1,
+                                       repetition_penalty=10.0, use_graph=graph)
+        runs[graph] = codes.cpu().numpy()
+        assert runs[graph].shape == (1, M)
+    assert np.array_equal(runs[True], runs[False])
+    assert len(np.unique(runs[True])) > 50                      # not a degenerate loop
+    tw = {k: torch.from_numpy(v) for k, v in uv.effective_state_dict.items()}
+    ref = og.generate_greedy(tw, cfg.gpt, og.conds_latent(tw, cfg.gpt, c.spk_cond_latent, emo), text, 24, 10.0)
+    assert np.array_equal(runs[True][:, :24], ref.numpy())
+
+
+def test_config4_estimator_at_full_length_vs_oracle(device, full):
+    """One DiT + WaveNet evaluation at T = 689 + 2580 frames (30 s of audio behind an 8 s prompt), full width, against the CPU oracle."""
+    from indextts_amd import _lib
+    from indextts_amd.s2mel import S2Mel
+    from oracle import s2mel as osm
+    cfg, wg, ws, wv = full
+    sm = S2Mel(ws, cfg.s2mel, device=device)
+    tws = {k: torch.from_numpy(v) for k, v in ws.items()}
+    Tp, T = 689, 689 + 2580
+    C = cfg.s2mel.in_channels
+    x = torch.from_numpy(synth.uniform("t/full/dit/x", (1, C, T), 1.0))
+    x[..., :Tp] = 0
+    px = torch.zeros(1, C, T)
+    px[..., :Tp] = torch.from_numpy(synth.uniform("t/full/dit/p", (1, C, Tp), 2.6, -4.0))
+    st = torch.from_numpy(synth.uniform("t/full/dit/style", (1, cfg.s2mel.style_dim), 1.0))
+    mu = torch.from_numpy(synth.uniform("t/full/dit/mu", (1, T, cfg.s2mel.content_dim), 1.0))
+    t = torch.tensor([0.45])
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        want = osm.dit_forward(tws, cfg.s2mel, x, px, torch.LongTensor([T]), t, st, mu)
+    scale = max(1.0, want.abs().max().item())
+    try:
+        for mode, tol in ((_lib.GEMM_F32, 2e-4), (_lib.GEMM_BF16X3, 1e-3)):
+            _lib.set_gemm_mode(mode)
+            got = sm.estimator(x, px, torch.LongTensor([T]), t, st, mu, prompt_lens=[Tp]).cpu()
+            err = (got - want).abs()
+            assert err.max().item() <= tol * scale and err.mean().item() <= 0.1 * tol * scale, (mode, err.max().item(), err.mean().item())
+    finally:
+        _lib.set_gemm_mode(_lib.GEMM_BF16X3)
+
+
+def test_config4_vocoder_2580_frames_locality_vs_oracle(device, full):
+    """BigVGAN on 2580 mel frames (30 s): an interior stretch of the waveform equals the CPU oracle run on a window of the mel
+    around it (the vocoder's receptive field is finite: < 64 frames), both arithmetic modes."""
+    from indextts_amd import _lib
+    from indextts_amd.vocoder import BigVGAN
+    from oracle import vocoder as ov
+    cfg, wg, ws, wv = full
+    voc = BigVGAN(wv, cfg.bigvgan)
+    Tm, lo, hi, margin = 2580, 1200, 1392, 64
+    mel = torch.from_numpy(weights.synth_mel("t/full/mel2580", 1, cfg.bigvgan.num_mels, Tm))
+    torch.set_num_threads(16)
+    wt = {k: torch.from_numpy(v) for k, v in wv.items()}
+    with torch.no_grad():
+        want = ov.bigvgan_forward(wt, cfg.bigvgan, mel[:, :, lo:hi])
+    up = cfg.bigvgan.total_upsample
+    a, b = margin * up, (hi - lo - margin) * up
+    try:
+        for mode, tol in ((_lib.GEMM_F32, 2e-4), (_lib.GEMM_BF16X3, 1.6e-3)):
+            _lib.set_gemm_mode(mode)
+            got = voc(mel.to(device)).cpu()
+            assert got.shape == (1, 1, Tm * up)
+            err = (got[..., lo * up + a: lo * up + b] - want[..., a:b]).abs().max().item()
+            assert err <= tol, (mode, err)
+    finally:
+        _lib.set_gemm_mode(_lib.GEMM_BF16X3)
+
+
+def test_config2_batch16_rows_equal_their_solo_runs(device, full):
+    """configs[2] at full size (16 utterances x 128 text tokens x 512 codes, greedy): rows 3 and 11 of the batch produce the codes of
+    their own B = 1 runs bit for bit, and mel within the north-star bound (L1 <= 1e-3) of the solo pipeline on the same noise rows."""
+    from indextts_amd.infer_v2 import IndexTTS2
+    cfg, wg, ws, wv = full
+    tts = IndexTTS2.from_state_dicts(cfg, wg, ws, wv, device=device)
+    c = _cond(cfg)
+    B, L, M, Tp = 16, 128, 512, 689
+    text = torch.from_numpy(synth.integers("bench/text/rank0", (B, L), 2, cfg.gpt.number_text_tokens))
+    Tg = int(M * cfg.code_to_frame)
+    noise = torch.from_numpy(synth.uniform("bench/noise/rank0", (B, cfg.s2mel.in_channels, Tp + Tg), 1.7)).to(device)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wavs, mid = tts.synthesize_batch(text, c, max_mel_tokens=M, noise=noise, return_intermediates=True)
+        assert mid["codes"].shape == (B, M) and all(n == M for n in mid["code_lens"])
+        for b in (3, 11):
+            w1, m1 = tts.synthesize_batch(text[b:b + 1], c, max_mel_tokens=M, noise=noise[b:b + 1], return_intermediates=True)
+            assert torch.equal(m1["codes"][0], mid["codes"][b])
+            l1 = (m1["mel"][0] - mid["mel"][b]).abs().mean().item()
+            assert l1 <= 1e-3, l1
+            assert (w1[0] - wavs[b]).abs().max().item() <= 32767 * 2e-3
+    assert all(torch.isfinite(w).all() for w in wavs)

@@ -60,11 +60,12 @@ def test_infer_return_contract(device, tmp_path):
     from indextts_amd.infer_v2 import InferenceResult
     cfg, wg, ws, wv, tts, cond = _build(device, eos_bias=6.5)
     seg = synth.integers("t/pipe/seg", (2, 6), 2, cfg.gpt.number_text_tokens).tolist()
-    sr, wav = tts.infer(cond, seg, None, max_mel_tokens=16)
+    G = dict(do_sample=False, num_beams=1)          # greedy: the parity mode (the defaults are the reference's beam-sample, below)
+    sr, wav = tts.infer(cond, seg, None, max_mel_tokens=16, **G)
     assert sr == 22050 and wav.dtype == np.int16 and wav.ndim == 2 and wav.shape[1] == 1
-    res = tts.infer(cond, seg[0], None, return_audio=True, return_numpy=True, max_mel_tokens=16)
+    res = tts.infer(cond, seg[0], None, return_audio=True, return_numpy=True, max_mel_tokens=16, **G)
     assert isinstance(res, InferenceResult) and res.sampling_rate == 22050 and res.duration_sec > 0 and res.rtf > 0
-    path = tts.infer(cond, seg[0], str(tmp_path / "o.wav"), max_mel_tokens=16)
+    path = tts.infer(cond, seg[0], str(tmp_path / "o.wav"), max_mel_tokens=16, **G)
     assert path.endswith("o.wav")
     import wave
     with wave.open(path) as f:
@@ -74,8 +75,8 @@ def test_infer_return_contract(device, tmp_path):
         list(tts.infer(cond, seg[0], None, stream_return=True, return_audio=True))      # a generator: raises on first use, as the reference
     with pytest.raises(NotImplementedError):
         tts.infer("examples/voice_01.wav", seg[0], None)
-    with pytest.raises(NotImplementedError):
-        tts.infer(cond, seg[0], None, num_beams=3, max_mel_tokens=16)
+    with pytest.raises(TypeError):
+        tts.infer(cond, seg[0], None, max_mel_tokens=16, no_such_kwarg=1)
     # the reference's sampling kwargs (num_beams=1): seeded draws make the run reproducible, and it differs from greedy
     torch.manual_seed(7)       # the CFM noise comes from the global RNG (reference: torch.randn in flow_matching.py:62)
     a = tts.infer(cond, seg[0], None, max_mel_tokens=16, do_sample=True, top_p=0.8, top_k=30, temperature=0.8, num_beams=1,
@@ -86,6 +87,67 @@ def test_infer_return_contract(device, tmp_path):
     assert a[0] == 22050 and np.array_equal(a[1], b[1])
 
 
+def test_infer_defaults_are_the_references_beam_sample(device):
+    """infer() with no generation kwargs = the reference's defaults (infer_v2.py:714-722): do_sample, num_beams=3, top_p .8,
+    top_k 30, temperature .8, repetition_penalty 10, length_penalty 0.  Repeatable under torch.manual_seed, equal to the explicit
+    spelling of those defaults, different from greedy, and -- with a torch generator -- equal to the CPU oracle's beam-sample."""
+    from oracle import gpt as og
+    cfg, wg, ws, wv, tts, cond = _build(device, eos_bias=2.0)
+    seg = synth.integers("t/pipe/beam", (1, 9), 2, cfg.gpt.number_text_tokens).tolist()[0]
+
+    def run(**kw):
+        torch.manual_seed(3)
+        return tts.infer(cond, seg, None, max_mel_tokens=20, **kw)[1]
+    a, b = run(), run()
+    assert np.array_equal(a, b)
+    c = run(do_sample=True, num_beams=3, top_p=0.8, top_k=30, temperature=0.8, repetition_penalty=10.0, length_penalty=0.0)
+    assert np.array_equal(a, c)
+    g = run(do_sample=False, num_beams=1)
+    assert a.shape != g.shape or not np.array_equal(a, g)
+    # token-level: the GPT stage under an explicit torch generator == the oracle fed the same draws
+    text = torch.tensor([seg])
+    NEW, nb, V = 20, 3, cfg.gpt.number_mel_codes
+    gen = torch.Generator().manual_seed(99)
+    noise = torch.stack([torch.empty(1, nb * V).exponential_(1, generator=gen) for _ in range(NEW)])
+    codes, _ = tts.gpt.inference_speech(cond.spk_cond_latent, text, emo_vec=cond.emo_vec, max_generate_length=NEW, do_sample=True, num_beams=3,
+                                        top_p=0.8, top_k=30, temperature=0.8, repetition_penalty=10.0, length_penalty=0.0,
+                                        generator=torch.Generator().manual_seed(99))
+    twg = {k: torch.from_numpy(v) for k, v in wg.items()}
+    want = og.generate_beam(twg, cfg.gpt, og.conds_latent(twg, cfg.gpt, cond.spk_cond_latent, cond.emo_vec), text, NEW, noise, num_beams=nb)
+    assert np.array_equal(codes.cpu().numpy(), want.numpy())
+
+
+def test_infer_from_prompt_features_hoists_the_conditioning(device):
+    """A PromptFeatures prompt: conformer + perceiver + merge_emovec run ONCE on the GPU (cached per prompt / emotion prompt / alpha),
+    and the result equals infer() on the PromptConditioning those encoders produce."""
+    from indextts_amd.infer_v2 import IndexTTS2, PromptConditioning, PromptFeatures
+    cfg = PipelineConfig.tiny()
+    wg = weights.synth_gpt_weights(cfg.gpt, tag="t/pipe/gpt")
+    wg.update(weights.synth_gpt_cond_weights(cfg.gpt, tag="t/pipe/gpt"))
+    wg["mel_head.bias"] = wg["mel_head.bias"].copy()
+    wg["mel_head.bias"][cfg.gpt.stop_mel_token] = 6.5
+    tts = IndexTTS2.from_state_dicts(cfg, wg, weights.synth_s2mel_weights(cfg.s2mel, tag="t/pipe/s2mel"),
+                                     weights.synth_bigvgan_weights(cfg.bigvgan, tag="t/pipe/voc"), device=device)
+    feats = PromptFeatures.synthetic(cfg, prompt_frames=11, feat_frames=31, tag="t/pipe/feats")
+    emo = PromptFeatures.synthetic(cfg, prompt_frames=11, feat_frames=27, tag="t/pipe/emo")
+    seg = synth.integers("t/pipe/fseg", (2, 6), 2, cfg.gpt.number_text_tokens).tolist()
+    G = dict(do_sample=False, num_beams=1, max_mel_tokens=16)
+    torch.manual_seed(5)
+    _, a = tts.infer(feats, seg, None, emo_audio_prompt=emo, emo_alpha=0.6, **G)
+    key = tts._cond_cache_key
+    torch.manual_seed(5)
+    _, a2 = tts.infer(feats, seg, None, emo_audio_prompt=emo, emo_alpha=0.6, **G)
+    assert tts._cond_cache_key == key and np.array_equal(a, a2)
+    both = PromptFeatures(feats.spk_cond_emb, feats.style, feats.prompt_condition, feats.ref_mel, emo.spk_cond_emb)
+    cond = PromptConditioning.from_features(tts.gpt, both, emo_alpha=0.6)
+    torch.manual_seed(5)
+    _, b = tts.infer(cond, seg, None, **G)
+    assert np.array_equal(a, b)
+    torch.manual_seed(5)
+    _, c = tts.infer(feats, seg, None, **G)                      # no emotion prompt: the speaker prompt serves (infer_v2.py:583-584)
+    assert c.shape != a.shape or not np.array_equal(a, c)
+
+
 def test_infer_streaming_contract(device):
     """stream_return (infer_v2.py:547-555, 874-886): a generator that yields, per segment, the segment's waveform ([1, n] float32
     on the CPU, scaled and clamped) and then the inter-segment silence -- and nothing else; joined, the chunks are the
@@ -93,10 +155,11 @@ def test_infer_streaming_contract(device):
     import types
     cfg, wg, ws, wv, tts, cond = _build(device, eos_bias=6.5)
     seg = synth.integers("t/pipe/stream", (3, 6), 2, cfg.gpt.number_text_tokens).tolist()
+    G = dict(do_sample=False, num_beams=1)
     torch.manual_seed(11)
-    sr, whole = tts.infer(cond, seg, None, max_mel_tokens=16, interval_silence=100)
+    sr, whole = tts.infer(cond, seg, None, max_mel_tokens=16, interval_silence=100, **G)
     torch.manual_seed(11)
-    gen = tts.infer(cond, seg, None, max_mel_tokens=16, interval_silence=100, stream_return=True)
+    gen = tts.infer(cond, seg, None, max_mel_tokens=16, interval_silence=100, stream_return=True, **G)
     assert isinstance(gen, types.GeneratorType)
     chunks = list(gen)
     assert len(chunks) == 2 * len(seg)
@@ -114,11 +177,11 @@ def test_infer_streaming_contract(device):
     assert np.abs(joined.astype(np.int32) - whole.astype(np.int32)).max() <= 3
     tts.segment_batch = 1                      # the reference's loop as written: bit for bit the streamed chunks
     torch.manual_seed(11)
-    _, seq = tts.infer(cond, seg, None, max_mel_tokens=16, interval_silence=100)
+    _, seq = tts.infer(cond, seg, None, max_mel_tokens=16, interval_silence=100, **G)
     assert np.array_equal(joined, seq)
     tts.segment_batch = 2                      # 3 segments as a batch of 2 and a batch of 1
     torch.manual_seed(11)
-    _, two = tts.infer(cond, seg, None, max_mel_tokens=16, interval_silence=100)
+    _, two = tts.infer(cond, seg, None, max_mel_tokens=16, interval_silence=100, **G)
     assert two.shape == whole.shape and np.abs(two.astype(np.int32) - whole.astype(np.int32)).max() <= 3
     assert list(tts.infer(cond, [], None, stream_return=True)) == []
 
