@@ -88,6 +88,7 @@ struct GemmV2P {
   const __bf16* b_hi; const __bf16* b_lo;   // [K/16][npad][16]
   const __bf16* zeros;           // >= 32 bytes of zeros (rows outside M / outside the sequence)
   int a_rows, npad, nstages;
+  int persist_n;                 // 1: grid = 8 * mt8 workgroups, each walks ALL column blocks of its 256-row tile (capped grid, see below)
 };
 
 #define GLDS16(gptr, lptr) \
@@ -106,7 +107,7 @@ template <> __device__ __forceinline__ void wait_vm_lgkm0<18>() { asm volatile("
 //   WNW = 1: 256 threads, 24 KiB stages, 3-deep ring, TWO workgroups per CU -- the waves that share a SIMD then belong to
 //            different workgroups with independent barriers, so one multiplies while the other waits / issues DMA.
 template <int WNW, int NSTAGE>
-__global__ __launch_bounds__(256 * WNW) void gemm_bf16x3_v2_kernel(const GemmV2P q) {
+__device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, const int bn, const int tid) {
   constexpr int NWV = 4 * WNW;                 // waves
   constexpr int BN = 128 * WNW;
   constexpr int A_PLANE = 256 * 32, B_PLANE = BN * 32;
@@ -116,13 +117,7 @@ __global__ __launch_bounds__(256 * WNW) void gemm_bf16x3_v2_kernel(const GemmV2P
   const GemmKP& p = q.g;
   extern __shared__ __attribute__((aligned(1024))) char smv2[];
 
-  const int L = blockIdx.x, xcd = L & 7, qq = L >> 3;
-  int bn, bm;
-  if (p.n_fast) { const int bml = qq / p.nblocks; bn = qq - bml * p.nblocks; bm = bml * 8 + xcd; }
-  else { bn = qq / p.mt8; bm = (qq - bn * p.mt8) * 8 + xcd; }
-  if (bm >= p.mtiles) return;
-
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wave = tid >> 6, lane = tid & 63;
   const int h = lane >> 5, j = lane & 31;
   const int wm = wave / WNW, wn = wave % WNW;
 
@@ -171,6 +166,12 @@ __global__ __launch_bounds__(256 * WNW) void gemm_bf16x3_v2_kernel(const GemmV2P
     }
   };
 
+  const int ns = q.nstages;
+  // fragment read offsets (bytes inside a plane image): row * 32 + (h ^ (row >> 3 & 1)) * 16, row = tile row of lane j
+  const int sw = (h ^ ((j >> 3) & 1)) * 16;
+  const int a_off = (wm * 64 + j) * 32 + sw;          // + t * 1024 for the second 32-row tile
+  const int b_offr = (wn * 128 + j) * 32 + sw;        // + t * 1024 per 32-column tile
+
   f32x16 acc[2][4];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -179,18 +180,12 @@ __global__ __launch_bounds__(256 * WNW) void gemm_bf16x3_v2_kernel(const GemmV2P
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-  const int ns = q.nstages;
 #pragma unroll
   for (int s = 0; s < NSTAGE; ++s)
     if (s < ns) {
 #pragma unroll
       for (int pi = 0; pi < PPW; ++pi) issue_piece(s, pi);
     }
-
-  // fragment read offsets (bytes inside a plane image): row * 32 + (h ^ (row >> 3 & 1)) * 16, row = tile row of lane j
-  const int sw = (h ^ ((j >> 3) & 1)) * 16;
-  const int a_off = (wm * 64 + j) * 32 + sw;          // + t * 1024 for the second 32-row tile
-  const int b_offr = (wn * 128 + j) * 32 + sw;        // + t * 1024 per 32-column tile
 
   struct Frag { bf16x8 ah[2], al[2], bh[4], bl[4]; };
   // stage s has landed for the whole workgroup: this wave's pieces by the counted wait (younger stages may stay in
@@ -269,6 +264,34 @@ __global__ __launch_bounds__(256 * WNW) void gemm_bf16x3_v2_kernel(const GemmV2P
   gemm_epilogue_lds<4, WNW, 2, 4>(p, acc, reinterpret_cast<float*>(smv2), bm * 256, bn * BN, wm, wn, wave, lane);
 }
 
+// one output tile per workgroup; XCD x owns the row tiles == x (mod 8) (gemm.hip explains the two walk orders)
+template <int WNW, int NSTAGE>
+__global__ __launch_bounds__(256 * WNW) void gemm_bf16x3_v2_kernel(const GemmV2P q) {
+  const GemmKP& p = q.g;
+  const int L = blockIdx.x, xcd = L & 7, qq = L >> 3;
+  int bn, bm;
+  if (p.n_fast) { const int bml = qq / p.nblocks; bn = qq - bml * p.nblocks; bm = bml * 8 + xcd; }
+  else { bn = qq / p.mt8; bm = (qq - bn * p.mt8) * 8 + xcd; }
+  if (bm >= p.mtiles) return;
+  gemm_v2_tile<WNW, NSTAGE>(q, bm, bn, threadIdx.x);
+}
+
+// Capped grid: one persistent workgroup per 256-row tile walks ALL its column blocks (the 25 workgroups of an XCD in step, so
+// they share each weight slice in their L2).  The tile body is the one above, re-entered per column block: the lane index goes
+// through an opaque zero so that nothing lane-derived is hoisted out of the loop and kept alive across the epilogue -- the
+// one-tile kernel sits at 255 VGPRs, loop-carried values would spill.
+template <int WNW, int NSTAGE>
+__global__ __launch_bounds__(256 * WNW) void gemm_bf16x3_v2_persist_kernel(const GemmV2P q) {
+  const int bm = (blockIdx.x >> 3) * 8 + (blockIdx.x & 7);
+  if (bm >= q.g.mtiles) return;
+  for (int bn = 0; bn < q.g.nblocks; ++bn) {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    gemm_v2_tile<WNW, NSTAGE>(q, bm, bn, threadIdx.x + z);
+    __syncthreads();      // the epilogue's LDS staging is read out before the next tile's DMA lands on it
+  }
+}
+
 // ---- per-stream scratch for the activation planes (grow-only) ----
 struct PlaneScratch { void* ptr = nullptr; size_t bytes = 0; };
 static std::map<hipStream_t, PlaneScratch> g_scratch;      // guarded by g_scratch_mu: stages of different batches may run on
@@ -333,7 +356,12 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
   q.b_lo = q.b_hi + (size_t)(w.K / 16) * q.npad * 16;
   q.zeros = g_zero_page;
   q.nstages = w.K / 16;
-  const int64_t grid = (int64_t)8 * q.g.nblocks * q.g.mt8;
+  // Capped grid (set_gemm_grid_cap): when another stage runs beside this one, 8 * mt8 workgroups (<= the cap) each walk all column
+  // blocks of their row tile, so the remaining CUs stay free for the other stream's short launches for the whole GEMM instead of
+  // being re-occupied by every wave of tiles; the work per workgroup is identical (no tail).
+  const int cap = get_gemm_grid_cap();
+  q.persist_n = (!narrow && cap > 0 && 8 * q.g.mt8 <= cap && 8 * q.g.mt8 >= cap / 2) ? 1 : 0;
+  const int64_t grid = q.persist_n ? (int64_t)8 * q.g.mt8 : (int64_t)8 * q.g.nblocks * q.g.mt8;
   IDX_CHECK(grid < (1ll << 31), "grid size");
   ProfScope prof(PROF_GEMM_BF16X3_256x256, stream, flops, bytes);
   if (narrow) {
@@ -351,7 +379,16 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
       IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v2_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16x3_v2_kernel<2, 4>), dim3((unsigned)grid), dim3(512), lds, stream, q);
+    if (q.persist_n) {
+      static bool attr_set_p = false;
+      if (!attr_set_p) {
+        IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v2_persist_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set_p = true;
+      }
+      hipLaunchKernelGGL((gemm_bf16x3_v2_persist_kernel<2, 4>), dim3((unsigned)grid), dim3(512), lds, stream, q);
+    } else {
+      hipLaunchKernelGGL((gemm_bf16x3_v2_kernel<2, 4>), dim3((unsigned)grid), dim3(512), lds, stream, q);
+    }
   }
   IDX_LAUNCH_CHECK();
   return 0;
