@@ -296,6 +296,9 @@ int idxtts_profile_enable(int on);
 int idxtts_profile_num_kernels(void);
 const char* idxtts_profile_kernel_name(int index);
 int idxtts_profile_read(int index, double* total_ms, double* flops, double* bytes, long* launches);
+/* Average reading of an event pair around one launch of an EMPTY 256-workgroup kernel on `stream`: the fixed per-launch cost
+ * of this timing method (subtract launches * overhead before comparing kernel families by time). */
+int idxtts_profile_event_overhead(void* stream, int launches, double* avg_ms);
 
 #ifdef __cplusplus
 }

@@ -53,12 +53,11 @@ static inline float bf2f(uint16_t b) {
 // [hl][K/16][Npad][16] planes of the LDS-DMA kernel (gemm_bf16x3_v2.hip)
 size_t linear_planes_bytes(int N, int K);
 void pack_linear_planes(void* dst, const float* w, int N, int K);
-bool gemm_bf16x3_v2_enabled();
 bool gemm_bf16x3_uses_v2(const LinearWeights& w, const GemmArgs& a);
 int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w, const GemmArgs& a, hipStream_t stream, double flops,
                            double bytes);
 bool gemm_bf16x3_uses_v2(const LinearWeights& w, const GemmArgs& a) {
-  return gemm_bf16x3_v2_enabled() && w.wp16 && a.M >= 4096 && w.N >= 192 && w.K % 16 == 0 && (a.taps <= 1 || (w.K / a.taps) % 16 == 0);
+  return w.wp16 && a.M >= 4096 && w.N >= 192 && w.K % 16 == 0 && (a.taps <= 1 || (w.K / a.taps) % 16 == 0);
 }
 static size_t tiles_bytes(int N, int K) { return (size_t)cdiv(N, 128) * cdiv(K, 32) * WTILE_BYTES; }
 size_t linear_bf16x3_packed_bytes(int N, int K) { return tiles_bytes(N, K) + linear_planes_bytes(N, K); }
@@ -395,10 +394,9 @@ int gemm_bf16x3_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t s
   const double bytes = 4.0 * ((double)a.M * w.K + (double)w.N * w.K + (double)a.M * w.N * (a.res ? 2.0 : 1.0));
   if (gemm_bf16x3_uses_v2(w, a))
     return gemm_bf16x3_v2_forward(p, static_cast<const char*>(w.wp16) + tiles_bytes(w.N, w.K), w, a, stream, flops, bytes);
-  static int tile_sel = getenv("IDXTTS_GEMM_TILE") ? atoi(getenv("IDXTTS_GEMM_TILE")) : 2;   // 0: 128x128, 1: 256x128, 2: 256x256
-  if (tile_sel >= 1 && a.M >= 4096) {
+  if (a.M >= 4096) {      // shapes the LDS-DMA kernel does not take (N < 192, K % 16 != 0): the register-staged 256-row tiles
     const bool paired = a.act == ACT_SWIGLU || a.act == ACT_GATE;
-    if (tile_sel == 2 && w.N >= 256 && !paired) return launch_big<4>(p, w, a, stream, flops, bytes);
+    if (w.N >= 256 && !paired) return launch_big<4>(p, w, a, stream, flops, bytes);
     return launch_big<2>(p, w, a, stream, flops, bytes);
   }
   constexpr size_t lds = (size_t)(2 * 2 * 2 * TILE_HALF) * sizeof(__bf16);

@@ -298,10 +298,6 @@ static std::map<hipStream_t, PlaneScratch> g_scratch;      // guarded by g_scrat
 static const __bf16* g_zero_page = nullptr;                 // different host threads / streams (bench.py's two-stage pipeline)
 static std::mutex g_scratch_mu;
 
-bool gemm_bf16x3_v2_enabled() {
-  static const bool on = !(getenv("IDXTTS_GEMM_V2") && atoi(getenv("IDXTTS_GEMM_V2")) == 0);
-  return on;
-}
 
 // p: fully prepared by gemm_bf16x3_forward (shapes, epilogue, conv parameters); planes: w.wp16 + offset
 int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w, const GemmArgs& a, hipStream_t stream, double flops,
@@ -343,10 +339,9 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
     IDX_CHECK(a.rope_T > 0 && a.rope_cols % 64 == 0 && a.act == ACT_NONE && (a.ldy & 3) == 0, "fused rotary arguments");
     q.g.rope = a.rope; q.g.rope_T = a.rope_T; q.g.rope_cols = a.rope_cols;
   }
-  // tile width: 256 columns on one 8-wave workgroup per CU, or 128 columns on two 4-wave workgroups per CU
-  static const int cfg_env = getenv("IDXTTS_V2_CFG") ? atoi(getenv("IDXTTS_V2_CFG")) : -1;
-  const bool narrow = cfg_env == 1;      // measured 1.5x slower on every hot-path shape (profiles/r01_gemm_bench.txt): kept for experiments
-  const int BN = narrow ? 128 : 256;
+  // tile width 256 columns on one 8-wave workgroup per CU (the 128-column / two-workgroup form measured 1.5x slower on every
+  // hot-path shape, profiles/r01_gemm_bench.txt, and is gone)
+  constexpr int BN = 256;
   q.g.mtiles = cdiv(a.M, 256);
   q.g.mt8 = cdiv(q.g.mtiles, 8);
   q.g.nblocks = cdiv(w.N, BN);
@@ -360,35 +355,25 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
   // blocks of their row tile, so the remaining CUs stay free for the other stream's short launches for the whole GEMM instead of
   // being re-occupied by every wave of tiles; the work per workgroup is identical (no tail).
   const int cap = get_gemm_grid_cap();
-  q.persist_n = (!narrow && cap > 0 && 8 * q.g.mt8 <= cap && 8 * q.g.mt8 >= cap / 2) ? 1 : 0;
+  q.persist_n = (cap > 0 && 8 * q.g.mt8 <= cap && 8 * q.g.mt8 >= cap / 2) ? 1 : 0;
   const int64_t grid = q.persist_n ? (int64_t)8 * q.g.mt8 : (int64_t)8 * q.g.nblocks * q.g.mt8;
   IDX_CHECK(grid < (1ll << 31), "grid size");
   ProfScope prof(PROF_GEMM_BF16X3_256x256, stream, flops, bytes);
-  if (narrow) {
-    constexpr int lds = 3 * (2 * 256 * 32 + 2 * 128 * 32);
-    static bool attr_set = false;
-    if (!attr_set) {
-      IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v2_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      attr_set = true;
+  constexpr int lds = 4 * (2 * 256 * 32 + 2 * 256 * 32);
+  static bool attr_set = false;
+  if (!attr_set) {
+    IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v2_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  if (q.persist_n) {
+    static bool attr_set_p = false;
+    if (!attr_set_p) {
+      IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v2_persist_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      attr_set_p = true;
     }
-    hipLaunchKernelGGL((gemm_bf16x3_v2_kernel<1, 3>), dim3((unsigned)grid), dim3(256), lds, stream, q);
+    hipLaunchKernelGGL((gemm_bf16x3_v2_persist_kernel<2, 4>), dim3((unsigned)grid), dim3(512), lds, stream, q);
   } else {
-    constexpr int lds = 4 * (2 * 256 * 32 + 2 * 256 * 32);
-    static bool attr_set = false;
-    if (!attr_set) {
-      IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v2_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      attr_set = true;
-    }
-    if (q.persist_n) {
-      static bool attr_set_p = false;
-      if (!attr_set_p) {
-        IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v2_persist_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set_p = true;
-      }
-      hipLaunchKernelGGL((gemm_bf16x3_v2_persist_kernel<2, 4>), dim3((unsigned)grid), dim3(512), lds, stream, q);
-    } else {
-      hipLaunchKernelGGL((gemm_bf16x3_v2_kernel<2, 4>), dim3((unsigned)grid), dim3(512), lds, stream, q);
-    }
+    hipLaunchKernelGGL((gemm_bf16x3_v2_kernel<2, 4>), dim3((unsigned)grid), dim3(512), lds, stream, q);
   }
   IDX_LAUNCH_CHECK();
   return 0;

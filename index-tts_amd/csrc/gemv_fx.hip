@@ -458,8 +458,6 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
 // workgroups per column tile; the partial sums go to a [ksb][rows][N] slab and gemv_fx_combine adds them in a fixed order
 // (bitwise reproducible) together with bias and residual.
 int gemv_fx_ksb(int N, int K) {
-  static const int forced = getenv("IDXTTS_FX_KSB") ? atoi(getenv("IDXTTS_FX_KSB")) : 0;
-  if (forced > 0) return (cdiv(K, 16) / forced >= 16) ? forced : 1;
   const int ntiles = cdiv(N, 16), kc16 = cdiv(K, 16);
   return (ntiles <= 128 && kc16 >= 64) ? 4 : 1;
 }
@@ -493,13 +491,10 @@ void gemv_fx_plan(int N, int K, int rows, int* ntw, int* kw) {
   const int kc16 = cdiv(K, 16), ntiles = cdiv(N, 16), MT = cdiv(rows, 16);
   int k = 16;
   while (k > 1 && kc16 < k) k >>= 1;
-  static const int kw_cap = getenv("IDXTTS_FX_KW") ? atoi(getenv("IDXTTS_FX_KW")) : 16;
-  while (k > kw_cap) k >>= 1;
   *kw = k;
   // Two column tiles per wave (one activation fragment feeds both) exactly when that turns a two-round launch into one
   // round of <= 256 workgroups (c_fc: 320 tiles); measured per shape in profiles/r01_gemv_probe.txt
-  static const int force_ntw = getenv("IDXTTS_FX_NTW") ? atoi(getenv("IDXTTS_FX_NTW")) : 0;
-  *ntw = force_ntw ? (MT == 1 ? force_ntw : 1) : ((MT == 1 && ntiles > 256 && cdiv(ntiles, 2) <= 256) ? 2 : 1);
+  *ntw = (MT == 1 && ntiles > 256 && cdiv(ntiles, 2) <= 256) ? 2 : 1;
 }
 
 int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t stream) {
@@ -551,8 +546,7 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
     else if (w.fmt == WFMT_BF16) LAUNCH_W(MTV, NTWV, SG, WFMT_BF16)                                                       \
     else LAUNCH_W(MTV, NTWV, SG, WFMT_F32)                                                                                \
   }
-  static const bool r4_on = !(getenv("IDXTTS_FX_R4") && atoi(getenv("IDXTTS_FX_R4")) == 0);
-  const bool r4 = r4_on && a.rows <= 4;
+  const bool r4 = a.rows <= 4;
   const bool single = p.cps <= 5;
   if (MT == 1 && ntw == 2 && single) LAUNCH(1, 2, true)
   else if (MT == 1 && ntw == 2) LAUNCH(1, 2, false)

@@ -352,12 +352,8 @@ int GPTModel::decode_step(const Buffers& w, int B, float penalty, long long* cod
     GemvFXArgs fb;      // x += mlp.c_proj(ff) + b
     fb.xf = w.ffd; fb.rows = B;
     const int ksb = gemv_fx_ksb(L.fc2_g.N, L.fc2_g.K);
-    static const bool unfused = getenv("IDXTTS_FX_UNFUSED") != nullptr;
-    if (ksb > 1 && unfused) {      // K split across workgroups (all 256 CUs stream), partial sums combined in a fixed order
-      fb.ksb = ksb; fb.y = w.slab; fb.ldy = d;
-      if (gemv_fx_forward(L.fc2_g, fb, st)) return 1;
-      if (gemv_fx_combine(w.slab, ksb, B, d, L.fc2_l.bias, w.xd, w.xd, st)) return 1;
-    } else if (ksb > 1) {          // ... by the last workgroup of each column tile to arrive (no combine launch)
+    if (ksb > 1) {          // K split across workgroups (all 256 CUs stream); the partial sums are combined in a fixed order by the
+                            // last workgroup of each column tile to arrive (no combine launch)
       fb.ksb = ksb; fb.slab = w.slab; fb.ksb_counters = w.ksb_cnt;
       fb.bias = L.fc2_l.bias; fb.res = w.xd; fb.y = w.xd; fb.y_frag = 1;
       if (gemv_fx_forward(L.fc2_g, fb, st)) return 1;

@@ -58,11 +58,35 @@ static void drain() {   // resolve recorded event pairs into per-family millisec
   g_recs.clear();
 }
 
+__global__ void prof_empty_kernel() {}
+
 }  // namespace idxtts
 
 using namespace idxtts;
 
 extern "C" {
+
+// What an event pair around ONE launch reads for a kernel that does nothing: the fixed cost the per-launch timing adds to
+// every launch (event records + dispatch), to be subtracted before families made of thousands of 9-us launches are compared
+// with families of a few 300-us launches.
+int idxtts_profile_event_overhead(void* stream, int launches, double* avg_ms) {
+  if (!avg_ms || launches <= 0) return 1;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  std::vector<hipEvent_t> ev(2 * (size_t)launches);
+  for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return 1;
+  for (int i = 0; i < 8; ++i) hipLaunchKernelGGL(prof_empty_kernel, dim3(256), dim3(256), 0, st);
+  for (int i = 0; i < launches; ++i) {
+    (void)hipEventRecord(ev[2 * i], st);
+    hipLaunchKernelGGL(prof_empty_kernel, dim3(256), dim3(256), 0, st);
+    (void)hipEventRecord(ev[2 * i + 1], st);
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) return 1;
+  double tot = 0.0;
+  for (int i = 0; i < launches; ++i) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]); tot += ms; }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  *avg_ms = tot / launches;
+  return 0;
+}
 
 int idxtts_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_mu);

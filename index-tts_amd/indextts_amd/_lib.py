@@ -19,7 +19,7 @@ SYMBOLS = [
     "idxtts_ctx_load_tensor", "idxtts_ctx_finalize", "idxtts_ctx_get_tensor", "idxtts_ctx_destroy",
     "idxtts_fp8_e4m3_decode", "idxtts_fp8_e4m3_encode",
     "idxtts_bigvgan_create", "idxtts_bigvgan_workspace_bytes", "idxtts_bigvgan_fwd", "idxtts_bigvgan_fwd_ragged",
-    "idxtts_profile_enable", "idxtts_profile_num_kernels", "idxtts_profile_kernel_name", "idxtts_profile_read",
+    "idxtts_profile_enable", "idxtts_profile_num_kernels", "idxtts_profile_kernel_name", "idxtts_profile_read", "idxtts_profile_event_overhead",
     "idxtts_linear_create", "idxtts_linear_fwd", "idxtts_linear_destroy", "idxtts_attention_fwd", "idxtts_attention_bf16x3_fwd", "idxtts_layernorm_fwd",
     "idxtts_gpt_create", "idxtts_gpt_quantize_weights", "idxtts_gpt_workspace_bytes", "idxtts_gpt_embed", "idxtts_gpt_generate", "idxtts_gpt_generate_sampled", "idxtts_gpt_latent",
     "idxtts_gpt_beam_workspace_bytes", "idxtts_gpt_generate_beam",
@@ -203,6 +203,15 @@ def get_tensor(ctx: c_void_p, name: str, shape):
 
 def profile_enable(on: bool) -> None:
     check(load().idxtts_profile_enable(int(on)))
+
+
+def profile_event_overhead(launches: int = 200) -> float:
+    """ms an event pair reads around one launch of an empty kernel on the current stream (fixed cost of the per-launch timing)."""
+    out = ctypes.c_double()
+    lib = load()
+    lib.idxtts_profile_event_overhead.argtypes = [c_void_p, c_int, POINTER(ctypes.c_double)]
+    check(lib.idxtts_profile_event_overhead(current_stream(), int(launches), ctypes.byref(out)))
+    return out.value
 
 
 def profile_read() -> dict:

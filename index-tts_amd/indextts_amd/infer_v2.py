@@ -127,9 +127,10 @@ class IndexTTS2:
         missing = [p for p in need if not os.path.exists(p)]
         if missing:
             raise FileNotFoundError(f"IndexTTS-2 checkpoints not found ({missing}); use IndexTTS2.from_state_dicts(...)")
-        from .checkpoint import load_reference_checkpoints
-        gpt_sd, s2mel_sd, voc_sd = load_reference_checkpoints(model_dir)
-        self._init(PipelineConfig(), gpt_sd, s2mel_sd, voc_sd, device, gpt_weight_format)
+        from .checkpoint import config_from_yaml, load_reference_checkpoints
+        cfg, raw = config_from_yaml(cfg_path) if os.path.exists(cfg_path) else (PipelineConfig(), None)
+        gpt_sd, s2mel_sd, voc_sd = load_reference_checkpoints(model_dir, raw)
+        self._init(cfg, gpt_sd, s2mel_sd, voc_sd, device, gpt_weight_format)
 
     @classmethod
     def from_state_dicts(cls, cfg: PipelineConfig, gpt_sd, s2mel_sd, bigvgan_sd, device=None, gpt_weight_format="f32",

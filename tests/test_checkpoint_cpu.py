@@ -46,8 +46,14 @@ def test_reference_checkpoint_layouts_round_trip(tmp_path):
            for sub, sd in net.items()}
     assert any(k.endswith("weight_g") for k in net["cfm"]), "fixture should contain weight-normed WaveNet layers"
     torch.save({"net": net}, tmp_path / "s2mel.pth")
-    save_file(codec, str(tmp_path / "semantic_codec.safetensors"))
-    torch.save({"generator": _split_weight_norm(wv, conv3)}, tmp_path / "bigvgan_generator.pt")
+    # the semantic codec and the vocoder in a hub CACHE laid out as huggingface_hub lays it out (the reference finds them with
+    # hf_hub_download / from_pretrained under HF_HUB_CACHE, infer_v2.py:5, 214, 260); nothing is downloaded
+    snap = tmp_path / "hf_cache" / "models--amphion--MaskGCT" / "snapshots" / "0123abcd" / "semantic_codec"
+    snap.mkdir(parents=True)
+    save_file(codec, str(snap / "model.safetensors"))
+    vsnap = tmp_path / "hf_cache" / "models--nvidia--bigvgan_v2_22khz_80band_256x" / "snapshots" / "fedc9876"
+    vsnap.mkdir(parents=True)
+    torch.save({"generator": _split_weight_norm(wv, conv3)}, vsnap / "bigvgan_generator.pt")
 
     gpt, s2mel, voc = load_reference_checkpoints(str(tmp_path))
     for got, want, name in ((gpt, wg, "gpt"), (s2mel, ws, "s2mel"), (voc, wv, "bigvgan")):
@@ -64,3 +70,29 @@ def test_fold_weight_norm_matches_torch():
         assert any(k.endswith("weight_g") for k in sd)
         folded = fold_weight_norm(sd)
         assert torch.allclose(folded["weight"], m.weight.detach(), atol=1e-6)
+
+
+def test_config_from_reference_yaml(tmp_path):
+    """cfg_path: the dimensions come from checkpoints/config.yaml (its gpt / s2mel / semantic_codec sections); written here with the
+    values of the reference's file, which equal PipelineConfig's defaults."""
+    import yaml
+    from indextts_amd.checkpoint import config_from_yaml
+    ref = {"gpt": {"model_dim": 1280, "max_mel_tokens": 1815, "max_text_tokens": 600, "heads": 20, "layers": 24, "number_text_tokens": 12000,
+                   "number_mel_codes": 8194, "start_mel_token": 8192, "stop_mel_token": 8193, "start_text_token": 0, "stop_text_token": 1,
+                   "condition_module": {"output_size": 512, "linear_units": 2048, "attention_heads": 8, "num_blocks": 6, "input_layer": "conv2d2", "perceiver_mult": 2},
+                   "emo_condition_module": {"output_size": 512, "linear_units": 1024, "attention_heads": 4, "num_blocks": 4, "input_layer": "conv2d2", "perceiver_mult": 2}},
+           "semantic_codec": {"codebook_size": 8192, "hidden_size": 1024, "codebook_dim": 8},
+           "s2mel": {"style_encoder": {"dim": 192},
+                     "length_regulator": {"channels": 512, "in_channels": 1024, "sampling_ratios": [1, 1, 1, 1]},
+                     "DiT": {"hidden_dim": 512, "num_heads": 8, "depth": 13, "in_channels": 80, "content_dim": 512},
+                     "wavenet": {"hidden_dim": 512, "num_layers": 8, "kernel_size": 5, "dilation_rate": 1}},
+           "gpt_checkpoint": "gpt.pth", "s2mel_checkpoint": "s2mel.pth", "vocoder": {"type": "bigvgan", "name": "nvidia/bigvgan_v2_22khz_80band_256x"}}
+    path = tmp_path / "config.yaml"
+    path.write_text(yaml.safe_dump(ref))
+    cfg, raw = config_from_yaml(str(path))
+    want = PipelineConfig()
+    assert cfg.gpt == want.gpt and cfg.s2mel.hidden_dim == want.s2mel.hidden_dim and cfg.s2mel.ffn_dim == want.s2mel.ffn_dim
+    assert cfg.s2mel.lr_num_convs == 4 and cfg.s2mel.codebook_size == 8192 and raw["vocoder"]["name"].startswith("nvidia/")
+    ref["gpt"]["layers"] = 12
+    path.write_text(yaml.safe_dump(ref))
+    assert config_from_yaml(str(path))[0].gpt.layers == 12
