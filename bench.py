@@ -397,8 +397,7 @@ def main() -> int:
     roofline = stages = None
     if rank == 0 and not args.no_roofline:
         # same work again with per-launch HIP events on the launch stream (graph replay is bypassed while profiling)
-        overhead_ms = _lib.profile_event_overhead(400)
-        log(f"[bench] event-pair reading around an empty launch: {1000 * overhead_ms:.2f} us")
+        empty_ms = _lib.profile_event_overhead(400)
         _lib.profile_enable(True)
         nprof = min(args.steps, 2)
         for _ in range(nprof):
@@ -408,11 +407,20 @@ def main() -> int:
         _lib.profile_enable(False)
         default_cfg = (not args.longform and args.gpt_weights == "f32" and args.gemm == "bf16x3" and (args.batch or 16) == 16
                        and args.codes == 512 and args.text_tokens == 128 and args.prompt_frames == 689)
-        roofline = roofline_from_profile(prof, nprof, args.workload, split_bf16=args.gemm != "f32", default_config=default_cfg,
-                                         overhead_ms=overhead_ms)
         if stage_times_fn is not None:   # device-synchronised timers behind the reference's four stage names (infer_v2.py:895-901)
             stages = {k: round(v, 4) for k, v in stage_times_fn().items()}
             log(f"[bench] stage seconds (synchronised, one step): {stages}")
+        # What bracketing every launch with an event pair adds per launch: the bracketed readings of a step sum to more than the
+        # same step takes un-bracketed (device-synchronised stage timers); the excess, spread over the launches, is the method's
+        # fixed cost -- never more than what the pair reads around an empty kernel.
+        overhead_ms = 0.0
+        if stages:
+            raw_ms = sum(v["ms"] for v in prof.values()) / nprof
+            n_launch = sum(v["launches"] for v in prof.values()) / nprof
+            overhead_ms = min(empty_ms, max(0.0, (raw_ms - 1000.0 * sum(stages.values())) / max(1.0, n_launch)))
+        log(f"[bench] event-pair reading around an empty launch {1000 * empty_ms:.2f} us; per-launch cost of the bracketing {1000 * overhead_ms:.2f} us")
+        roofline = roofline_from_profile(prof, nprof, args.workload, split_bf16=args.gemm != "f32", default_config=default_cfg,
+                                         overhead_ms=overhead_ms)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

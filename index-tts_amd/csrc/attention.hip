@@ -329,11 +329,15 @@ __global__ __launch_bounds__(256) void flash_attn_bf16x3_kernel(const AttnArgs p
         psum += pv;
       }
       l_run = l_run * alpha + psum;
+      // the running maximum moves in the first few tiles and then rarely: when no lane's maximum moved (alpha == 1 everywhere,
+      // wave-uniform test) the 32 accumulator rescales are skipped -- same bits, a ninth of the loop's VALU work less
+      if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      }
       m_run = m_new;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
       // ---- P^T operands: registers 8 t2 .. 8 t2 + 7 are the k-slots of MFMA t2 ----
       bf16x8 ph[2], pl[2];
 #pragma unroll

@@ -25,6 +25,9 @@ struct CfmEulerArgs {    // x += dt*((1+cfg)*v_cond - cfg*v_null); x[:, :, :Tp] 
   const int* prompt_len;
   int B, T, C;
   float dt, cfg_rate;
+  // v may hold only the frames t >= v_t0 of every sequence (v_T of them): row (n, t) at n * v_T + (t - v_t0); frames t < v_t0 lie
+  // inside every prompt (x stays 0 there).  v_T = 0: all T frames (v_t0 = 0).
+  int v_t0 = 0, v_T = 0;
 };
 int cfm_euler(const CfmEulerArgs& a, hipStream_t st);
 
@@ -32,6 +35,8 @@ int cfm_euler(const CfmEulerArgs& a, hipStream_t st);
 // (length_regulator.py:51-54 nn.GroupNorm(groups=1) + nn.Mish, per-utterance statistics)
 int groupnorm1_mish(float* y, const float* x, const float* gamma, const float* beta, const int* row_len, int B, int T, int C,
                     float eps, float* stats /* [B][2] scratch */, hipStream_t st);
+// dst[(n, j)][:cols] = src[(n, t0 + j)][:cols], j < Tn: the frames t >= t0 of every sequence, compacted (row strides ld_dst / ld_src)
+int gather_tail_rows(float* dst, int ld_dst, const float* src, int ld_src, int cols, int N, int T, int t0, hipStream_t st);
 // x[b][c][t < zero_len[b]] = 0 and copy: used to initialise the Euler state
 int cfm_init_state(float* x, const float* z, const int* prompt_len, int B, int C, int T, hipStream_t st);
 

@@ -74,17 +74,38 @@ __global__ __launch_bounds__(256) void cfm_euler_kernel(const CfmEulerArgs p) {
   const int t = (int)(idx % p.T);
   const int c = (int)((idx / p.T) % p.C);
   const int b = (int)(idx / ((size_t)p.T * p.C));
-  const float vc = p.v[((size_t)b * p.T + t) * p.ldv + c];
-  const float vn = p.v[((size_t)(p.B + b) * p.T + t) * p.ldv + c];
+  if (t < p.prompt_len[b] || t < p.v_t0) { p.x[idx] = 0.0f; return; }
+  const int vT = p.v_T > 0 ? p.v_T : p.T, tv = t - p.v_t0;
+  const float vc = p.v[((size_t)b * vT + tv) * p.ldv + c];
+  const float vn = p.v[((size_t)(p.B + b) * vT + tv) * p.ldv + c];
   const float dphi = (1.0f + p.cfg_rate) * vc - p.cfg_rate * vn;
-  const float xn = p.x[idx] + p.dt * dphi;
-  p.x[idx] = t < p.prompt_len[b] ? 0.0f : xn;
+  p.x[idx] = p.x[idx] + p.dt * dphi;
 }
 
 int cfm_euler(const CfmEulerArgs& a, hipStream_t st) {
   const size_t total = (size_t)a.B * a.C * a.T;
   ProfScope prof(PROF_ELTWISE, st, 0.0, 16.0 * total);
   hipLaunchKernelGGL(cfm_euler_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, a);
+  IDX_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void gather_tail_rows_kernel(float* dst, int ld_dst, const float* src, int ld_src, int cols, int T, int t0, int Tn) {
+  const int j = blockIdx.x, n = blockIdx.y;
+  const float* s = src + ((size_t)n * T + t0 + j) * ld_src;
+  float* d = dst + ((size_t)n * Tn + j) * ld_dst;
+  if (((cols | ld_dst | ld_src) & 3) == 0) {
+    for (int e = threadIdx.x; e < cols / 4; e += 256) reinterpret_cast<f32x4*>(d)[e] = reinterpret_cast<const f32x4*>(s)[e];
+  } else {
+    for (int e = threadIdx.x; e < cols; e += 256) d[e] = s[e];
+  }
+}
+
+int gather_tail_rows(float* dst, int ld_dst, const float* src, int ld_src, int cols, int N, int T, int t0, hipStream_t st) {
+  IDX_CHECK(dst && src && t0 >= 0 && t0 < T && cols > 0, "gather_tail_rows args");
+  const int Tn = T - t0;
+  ProfScope prof(PROF_ELTWISE, st, 0.0, 8.0 * N * (double)Tn * cols);
+  hipLaunchKernelGGL(gather_tail_rows_kernel, dim3(Tn, N), dim3(256), 0, st, dst, ld_dst, src, ld_src, cols, T, t0, Tn);
   IDX_LAUNCH_CHECK();
   return 0;
 }

@@ -216,3 +216,35 @@ def test_cfm_long_batch_dma_gemm_chain_vs_oracle(device):
                                 z[b:b + 1, :, :Lb], 2, 0.7)
         err = (out[b, :, :Lb] - ref[0]).abs()
         assert err.mean().item() <= 1e-4 and err.max().item() <= 3e-3, (b, err.mean().item(), err.max().item())
+
+
+@pytest.mark.parametrize("lens,plens", [([720, 655, 701], [300, 260, 281]), ([1100, 1100], [400, 400])])
+def test_cfm_long_prompts_tail_only_wavenet_vs_oracle(device, lens, plens):
+    """Prompts longer than 64 frames + the WaveNet's context: the solver evaluates the post-transformer part (long skip, WaveNet,
+    final layer) only from frame min(prompt_len) - halo on, on compacted rows -- the Euler step discards the prompt frames anyway
+    (flow_matching.py:113).  Ragged batch vs the per-utterance CPU oracle; the second case keeps the compacted rows on the LDS-DMA
+    GEMM chain (>= 4096 rows), the first drops to the fp32-row kernels for the tail."""
+    import dataclasses
+    from indextts_amd.s2mel import S2Mel
+    from oracle import s2mel as osm
+    cfg = dataclasses.replace(S2MelConfig.tiny(), hidden_dim=512, num_heads=8, depth=3, wn_hidden=512, wn_layers=2, block_size=2048)
+    w = weights.synth_s2mel_weights(cfg, tag="t/s2mel/tail")
+    sm = S2Mel(w, cfg, device=device, max_frames=2048)
+    tw = {k: torch.from_numpy(v) for k, v in w.items()}
+    B, T, Tpm = len(lens), max(lens), max(plens)
+    z = torch.from_numpy(synth.uniform("t/s2mel/tail/z", (B, cfg.in_channels, T), 1.7))
+    mu = torch.from_numpy(synth.uniform("t/s2mel/tail/mu", (B, T, cfg.content_dim), 1.0))
+    prompt = torch.from_numpy(synth.uniform("t/s2mel/tail/prompt", (B, cfg.in_channels, Tpm), 1.0))
+    st = torch.from_numpy(synth.uniform("t/s2mel/tail/style", (B, cfg.style_dim), 1.0))
+    for b in range(B):
+        mu[b, lens[b]:] = 0
+    out = sm.cfm_inference(mu, torch.LongTensor(lens), prompt, st, None, 2, inference_cfg_rate=0.7, z=z,
+                           prompt_lens=torch.LongTensor(plens)).cpu()
+    torch.set_num_threads(16)
+    for b in range(B):
+        Lb, Pb = lens[b], plens[b]
+        ref = osm.cfm_inference(tw, cfg, mu[b:b + 1, :Lb], torch.LongTensor([Lb]), prompt[b:b + 1, :, :Pb], st[b:b + 1],
+                                z[b:b + 1, :, :Lb], 2, 0.7)
+        err = (out[b, :, :Lb] - ref[0]).abs()
+        assert err.max().item() <= 3e-3 and err.mean().item() <= 1e-4, (b, err.max().item(), err.mean().item())
+        assert (out[b, :, :Pb] == 0).all()
