@@ -76,11 +76,11 @@ def roofline_from_profile(prof, steps, workload="pipeline", split_bf16=True, def
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (separate --pmc FETCH_SIZE /
     # WRITE_SIZE runs, gfx950 correction applied; profiles/README.md) -- null when no pass is on file for this kernel
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic_r01.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "traffic_r02.json")) as f:
             tr = json.load(f)["kernels"].get(dom_name)
         if tr and workload == "pipeline" and default_config:      # the PMC passes on file are of the default configs[2] command
             r["traffic"] = tr["hbm_bytes_per_launch"]
-            r["traffic_source"] = "profiles/traffic_r01.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes = (2*FETCH+WRITE)*1024)"
+            r["traffic_source"] = "profiles/traffic_r02.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes = (2*FETCH+WRITE)*1024)"
     except (OSError, KeyError, ValueError):
         pass
     r["launches_per_step"] = dom["launches"] // steps
@@ -318,9 +318,9 @@ def main() -> int:
                     help="pipeline workload with stage overlap: cap on the workgroups of a split-bf16 GEMM launch (e.g. 208 of the 256 CUs: the "
                          "GEMMs of s2mel then run persistent workgroups and leave the other CUs to the decode's short launches; default 0 = no cap)")
     ap.add_argument("--gpt-weights", default=None, choices=["f32", "bf16", "fp8"],
-                    help="storage of the GPT linear weights (decode is bound by the weight stream): fp32 (default: the reference's "
-                         "own weights, bit for bit), bf16, or fp8-e4m3 with a power-of-two scale per output channel (BASELINE configs[4]); "
-                         "arithmetic stays fp32; the CPU baseline / parity leg runs the same rounded model")
+                    help="storage of the GPT linear weights: bf16 (default for the pipeline workload: what BASELINE configs[2] names), "
+                         "fp8-e4m3 with a power-of-two scale per output channel (default for longform = configs[4]), or f32 (the reference's "
+                         "own weights, bit for bit); arithmetic stays fp32; the CPU baseline / parity leg runs the same rounded model")
     ap.add_argument("--gemm", default="bf16x3", choices=["bf16x3", "f32"],
                     help="arithmetic of the GEMM-shaped passes (s2mel, latent pass): split-bf16 (default) or exact fp32 MFMA")
     args = ap.parse_args()
@@ -331,7 +331,10 @@ def main() -> int:
         args.workload = "pipeline"
         args.batch = args.batch or 1
     args.codes = args.codes or (1500 if longform else 512)
-    args.gpt_weights = args.gpt_weights or ("fp8" if longform else "f32")
+    # configs[2] names bf16 ("IndexTTS-2 full pipeline ... batch=16, 1xMI355X, bf16, greedy decode"), configs[4] fp8: the GPT's linear
+    # weights are STORED in that format (rounded once at load), the arithmetic stays fp32, and the parity leg runs the same rounded
+    # model on the CPU oracle.  --gpt-weights f32 keeps the reference's own weights bit for bit.
+    args.gpt_weights = args.gpt_weights or ("fp8" if longform else ("bf16" if args.workload == "pipeline" else "f32"))
     args.longform = longform
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -405,7 +408,7 @@ def main() -> int:
         torch.cuda.synchronize()
         prof = _lib.profile_read()
         _lib.profile_enable(False)
-        default_cfg = (not args.longform and args.gpt_weights == "f32" and args.gemm == "bf16x3" and (args.batch or 16) == 16
+        default_cfg = (not args.longform and args.gpt_weights == "bf16" and args.gemm == "bf16x3" and (args.batch or 16) == 16
                        and args.codes == 512 and args.text_tokens == 128 and args.prompt_frames == 689)
         if stage_times_fn is not None:   # device-synchronised timers behind the reference's four stage names (infer_v2.py:895-901)
             stages = {k: round(v, 4) for k, v in stage_times_fn().items()}
