@@ -265,7 +265,6 @@ def build_pipeline(args, world, rank, dev):
                         + ("" if not compact else f", GPT linear weights stored as {args.gpt_weights} (rounded once at load; fp32 arithmetic)"),
             "gpt_weights": args.gpt_weights,
             "batch_per_gpu": B, "text_tokens": L, "codes": M, "prompt_frames": Tp, "diffusion_steps": cfg.diffusion_steps}
-    desc["gemm_grid_cap"] = args.gemm_cap
     desc["step_overlap"] = ("none" if args.no_overlap else
                             "two-stage pipeline across steps: decode of batch k+1 overlaps s2mel+vocoder of batch k (two streams, one worker thread)")
     step.flush = (lambda: None) if args.no_overlap else flush
@@ -314,9 +313,6 @@ def main() -> int:
     ap.add_argument("--no-overlap", action="store_true",
                     help="pipeline workload: run the K steps strictly one after the other (default: the decode of step k+1 overlaps "
                          "the s2mel + vocoder stages of step k on a second stream)")
-    ap.add_argument("--gemm-cap", type=int, default=-1,
-                    help="pipeline workload with stage overlap: cap on the workgroups of a split-bf16 GEMM launch (e.g. 208 of the 256 CUs: the "
-                         "GEMMs of s2mel then run persistent workgroups and leave the other CUs to the decode's short launches; default 0 = no cap)")
     ap.add_argument("--gpt-weights", default=None, choices=["f32", "bf16", "fp8"],
                     help="storage of the GPT linear weights: bf16 (default for the pipeline workload: what BASELINE configs[2] names), "
                          "fp8-e4m3 with a power-of-two scale per output channel (default for longform = configs[4]), or f32 (the reference's "
@@ -361,9 +357,6 @@ def main() -> int:
     from indextts_amd import _lib
     _lib.load()
     _lib.set_gemm_mode(0 if args.gemm == "f32" else 1)
-    if args.gemm_cap < 0:
-        args.gemm_cap = 0       # measured: 105.5 (cap 208) vs 105.1 (no cap) audio-s/s with the overlap on -- within noise (profiles/README.md)
-    _lib.set_gemm_grid_cap(args.gemm_cap)
     t0 = time.time()
     build = build_pipeline if args.workload == "pipeline" else build_vocoder
     step, profiled, cpu_leg, stage_times_fn, audio_s_per_step_per_gpu, desc = build(args, world, rank, dev)

@@ -116,11 +116,6 @@ int idxtts_linear_fwd(const idxtts_linear* lin, const float* x, int ldx, float* 
  * reference).  The KV-cached greedy decode and its prefill are always exact fp32 (token indices are bit-exact in both modes). */
 int idxtts_set_gemm_mode(int mode);
 int idxtts_get_gemm_mode(void);
-/* Upper bound on the workgroups of one split-bf16 GEMM launch (0 = none, default).  For running two stages of the path side by side
- * on one GPU (decode of one batch beside s2mel + vocoder of another): with a cap (e.g. 208 of the 256 CUs) the GEMM runs
- * persistent workgroups -- one per 256-row tile, walking all its column blocks -- so the other CUs stay free for the concurrent
- * stream's many short launches instead of being re-filled by every wave of tiles.  Results are bit-identical. */
-int idxtts_set_gemm_grid_cap(int max_workgroups);
 int idxtts_linear_destroy(idxtts_linear* lin);
 /* Multi-head attention, head_dim 64, softmax(q k^T * scale + mask) v without materialising the scores.
  * q/k/v/o are read in place: element (b, t, h, e) at base + b*batch_stride + t*token_stride + 64*h + e.

@@ -489,9 +489,4 @@ int idxtts_set_gemm_mode(int mode) {
 
 int idxtts_get_gemm_mode(void) { return get_gemm_mode(); }
 
-int idxtts_set_gemm_grid_cap(int max_workgroups) {
-  set_gemm_grid_cap(max_workgroups);
-  return 0;
-}
-
 }  // extern "C"

@@ -58,11 +58,6 @@ void pack_linear_bf16x3(void* dst, const float* w, int N, int K);
 enum GemmMode { GEMM_F32 = 0, GEMM_BF16X3 = 1 };
 void set_gemm_mode(int mode);
 int get_gemm_mode();
-// Upper bound on the workgroups of one split-bf16 GEMM launch (0 = none, the default).  With a cap the LDS-DMA kernel runs
-// 8 * ceil(row tiles / 8) persistent workgroups (when that count lies in [cap / 2, cap]) that walk their row tile's column
-// blocks, leaving 256 - that many CUs free for a concurrent stream (bench.py's decode || s2mel overlap).
-void set_gemm_grid_cap(int max_workgroups);
-int get_gemm_grid_cap();
 // dispatches on the mode above
 int gemm_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t stream);
 // true when gemm_forward would run this shape on the LDS-DMA split-bf16 kernel (the only consumer / producer of planes)

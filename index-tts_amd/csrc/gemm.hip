@@ -229,10 +229,6 @@ static int g_gemm_mode = GEMM_BF16X3;
 void set_gemm_mode(int mode) { g_gemm_mode = mode == GEMM_F32 ? GEMM_F32 : GEMM_BF16X3; }
 int get_gemm_mode() { return g_gemm_mode; }
 
-static int g_gemm_grid_cap = 0;
-void set_gemm_grid_cap(int max_workgroups) { g_gemm_grid_cap = max_workgroups > 0 ? max_workgroups : 0; }
-int get_gemm_grid_cap() { return g_gemm_grid_cap; }
-
 bool gemm_bf16x3_uses_v2(const LinearWeights& w, const GemmArgs& a);
 bool gemm_uses_planes(const LinearWeights& w, const GemmArgs& a) {
   return g_gemm_mode == GEMM_BF16X3 && w.wp16 && a.M >= 256 && gemm_bf16x3_uses_v2(w, a);

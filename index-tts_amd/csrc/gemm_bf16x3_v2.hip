@@ -88,7 +88,6 @@ struct GemmV2P {
   const __bf16* b_hi; const __bf16* b_lo;   // [K/16][npad][16]
   const __bf16* zeros;           // >= 32 bytes of zeros (rows outside M / outside the sequence)
   int a_rows, npad, nstages;
-  int persist_n;                 // 1: grid = 8 * mt8 workgroups, each walks ALL column blocks of its 256-row tile (capped grid, see below)
 };
 
 #define GLDS16(gptr, lptr) \
@@ -276,22 +275,6 @@ __global__ __launch_bounds__(256 * WNW) void gemm_bf16x3_v2_kernel(const GemmV2P
   gemm_v2_tile<WNW, NSTAGE>(q, bm, bn, threadIdx.x);
 }
 
-// Capped grid: one persistent workgroup per 256-row tile walks ALL its column blocks (the 25 workgroups of an XCD in step, so
-// they share each weight slice in their L2).  The tile body is the one above, re-entered per column block: the lane index goes
-// through an opaque zero so that nothing lane-derived is hoisted out of the loop and kept alive across the epilogue -- the
-// one-tile kernel sits at 255 VGPRs, loop-carried values would spill.
-template <int WNW, int NSTAGE>
-__global__ __launch_bounds__(256 * WNW) void gemm_bf16x3_v2_persist_kernel(const GemmV2P q) {
-  const int bm = (blockIdx.x >> 3) * 8 + (blockIdx.x & 7);
-  if (bm >= q.g.mtiles) return;
-  for (int bn = 0; bn < q.g.nblocks; ++bn) {
-    int z;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-    gemm_v2_tile<WNW, NSTAGE>(q, bm, bn, threadIdx.x + z);
-    __syncthreads();      // the epilogue's LDS staging is read out before the next tile's DMA lands on it
-  }
-}
-
 // ---- per-stream scratch for the activation planes (grow-only) ----
 struct PlaneScratch { void* ptr = nullptr; size_t bytes = 0; };
 static std::map<hipStream_t, PlaneScratch> g_scratch;      // guarded by g_scratch_mu: stages of different batches may run on
@@ -351,12 +334,7 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
   q.b_lo = q.b_hi + (size_t)(w.K / 16) * q.npad * 16;
   q.zeros = g_zero_page;
   q.nstages = w.K / 16;
-  // Capped grid (set_gemm_grid_cap): when another stage runs beside this one, 8 * mt8 workgroups (<= the cap) each walk all column
-  // blocks of their row tile, so the remaining CUs stay free for the other stream's short launches for the whole GEMM instead of
-  // being re-occupied by every wave of tiles; the work per workgroup is identical (no tail).
-  const int cap = get_gemm_grid_cap();
-  q.persist_n = (cap > 0 && 8 * q.g.mt8 <= cap && 8 * q.g.mt8 >= cap / 2) ? 1 : 0;
-  const int64_t grid = q.persist_n ? (int64_t)8 * q.g.mt8 : (int64_t)8 * q.g.nblocks * q.g.mt8;
+  const int64_t grid = (int64_t)8 * q.g.nblocks * q.g.mt8;
   IDX_CHECK(grid < (1ll << 31), "grid size");
   ProfScope prof(PROF_GEMM_BF16X3_256x256, stream, flops, bytes);
   constexpr int lds = 4 * (2 * 256 * 32 + 2 * 256 * 32);
@@ -365,16 +343,7 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
     IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v2_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  if (q.persist_n) {
-    static bool attr_set_p = false;
-    if (!attr_set_p) {
-      IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v2_persist_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      attr_set_p = true;
-    }
-    hipLaunchKernelGGL((gemm_bf16x3_v2_persist_kernel<2, 4>), dim3((unsigned)grid), dim3(512), lds, stream, q);
-  } else {
-    hipLaunchKernelGGL((gemm_bf16x3_v2_kernel<2, 4>), dim3((unsigned)grid), dim3(512), lds, stream, q);
-  }
+  hipLaunchKernelGGL((gemm_bf16x3_v2_kernel<2, 4>), dim3((unsigned)grid), dim3(512), lds, stream, q);
   IDX_LAUNCH_CHECK();
   return 0;
 }

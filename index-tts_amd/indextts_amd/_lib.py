@@ -24,7 +24,7 @@ SYMBOLS = [
     "idxtts_gpt_create", "idxtts_gpt_quantize_weights", "idxtts_gpt_workspace_bytes", "idxtts_gpt_embed", "idxtts_gpt_generate", "idxtts_gpt_generate_sampled", "idxtts_gpt_latent",
     "idxtts_gpt_beam_workspace_bytes", "idxtts_gpt_generate_beam",
     "idxtts_s2mel_create", "idxtts_s2mel_cond_workspace_bytes", "idxtts_s2mel_prepare_cond",
-    "idxtts_s2mel_cfm_workspace_bytes", "idxtts_s2mel_cfm", "idxtts_set_gemm_mode", "idxtts_get_gemm_mode", "idxtts_set_gemm_grid_cap",
+    "idxtts_s2mel_cfm_workspace_bytes", "idxtts_s2mel_cfm", "idxtts_set_gemm_mode", "idxtts_get_gemm_mode",
     "idxtts_s2mel_estimator", "idxtts_cond_create", "idxtts_cond_workspace_bytes", "idxtts_cond_forward", "idxtts_emovec_merge",
 ]
 
@@ -107,7 +107,6 @@ def load() -> ctypes.CDLL:
     lib.idxtts_linear_create.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_void_p)]
     lib.idxtts_linear_fwd.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.idxtts_set_gemm_mode.argtypes = [c_int]
-    lib.idxtts_set_gemm_grid_cap.argtypes = [c_int]
     lib.idxtts_linear_destroy.argtypes = [c_void_p]
     lib.idxtts_attention_fwd.argtypes = [c_void_p] * 4 + [c_long, c_int, c_long, c_int, c_long, c_int, c_int, c_int, c_int, c_int,
                                                           c_int, c_void_p, c_void_p, c_float, c_void_p]
@@ -233,11 +232,6 @@ GEMM_F32, GEMM_BF16X3 = 0, 1
 def set_gemm_mode(mode: int) -> None:
     """0 = exact fp32 MFMA everywhere; 1 (library default) = split-bf16 for the GEMM-shaped passes with M >= 256."""
     check(load().idxtts_set_gemm_mode(int(mode)))
-
-
-def set_gemm_grid_cap(max_workgroups: int) -> None:
-    """Cap the workgroups of a split-bf16 GEMM launch (0 = no cap): see idxtts_set_gemm_grid_cap."""
-    check(load().idxtts_set_gemm_grid_cap(int(max_workgroups)))
 
 
 def get_gemm_mode() -> int:

@@ -69,25 +69,6 @@ def test_gemm_split_bf16_vs_torch(device, shape):
     assert err < 1e-3
 
 
-def test_gemm_capped_grid_is_bit_identical(device):
-    """idxtts_set_gemm_grid_cap: persistent workgroups walking the column blocks of their row tile give the same bits as the
-    one-tile-per-workgroup launch (same tile arithmetic, different schedule)."""
-    M, N, K = 16640, 1024, 512          # 65 row tiles -> 72 persistent workgroups x 4 column blocks under a cap of 128
-    x = torch.from_numpy(synth.uniform("t/gemmcap/x", (M, K), 1.0))
-    w = torch.from_numpy(synth.fan_in_uniform("t/gemmcap/w", (N, K), K))
-    b = torch.from_numpy(synth.uniform("t/gemmcap/b", (N,), 0.2))
-    r = torch.from_numpy(synth.uniform("t/gemmcap/r", (M, N), 1.0))
-    y0 = _linear(device, w, b, x, act=2, res=r, bf16x3=1)
-    try:
-        _lib.set_gemm_grid_cap(128)
-        y1 = _linear(device, w, b, x, act=2, res=r, bf16x3=1)
-    finally:
-        _lib.set_gemm_grid_cap(0)
-    assert torch.equal(y0, y1)
-    ref = (torch.nn.functional.silu(x.double() @ w.double().t() + b.double()) + r.double()).float()
-    assert (y1 - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
-
-
 def test_gemm_swiglu_and_silu(device):
     M, Hd, K = 200, 192, 64      # hidden 192 -> N = 384 packed as [32 w1 | 32 w3] blocks
     x = torch.from_numpy(synth.uniform("t/swiglu/x", (M, K), 1.0))

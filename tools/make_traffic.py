@@ -10,7 +10,7 @@ import json
 import sys
 
 CATEGORY = [            # (substring of the kernel symbol, bench.py category)
-    ("gemv_fx_kernel", "gemv16_mfma"), ("gemm_bf16x3_v2_kernel", "gemm_bf16x3_256x256"), ("gemm_bf16x3_v2_persist_kernel", "gemm_bf16x3_256x256"), ("gemm_bf16x3_big_kernel<4>", "gemm_bf16x3_256x256"),
+    ("gemv_fx_kernel", "gemv16_mfma"), ("gemm_bf16x3_v2_kernel", "gemm_bf16x3_256x256"), ("gemm_bf16x3_big_kernel<4>", "gemm_bf16x3_256x256"),
     ("gemm_bf16x3_big_kernel<2>", "gemm_bf16x3_256x128"), ("gemm_bf16x3_kernel", "gemm_bf16x3_128x128"), ("gemm_tn_kernel", "gemm_tn_128x128"),
     ("flash_attn", "flash_attn_f32"), ("decode_attn_kernel", "decode_attn"), ("conv1d_mfma_kernel<2, 2, 2, 2>", "conv1d_mfma_128x128"),
     ("conv1d_bf16x3_kernel<2, 2, 2, 2>", "conv1d_mfma_128x128"), ("conv1d_bf16x3_kernel<3, 2, 1, 4>", "conv1d_mfma_96x256"),
