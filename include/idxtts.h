@@ -264,6 +264,11 @@ size_t idxtts_s2mel_cond_workspace_bytes(const idxtts_ctx* ctx, int B, int M, in
 int idxtts_s2mel_prepare_cond(idxtts_ctx* ctx, const float* latent, const long long* codes, const int* code_lens,
                               const int* target_lens, int B, int M, int Tg, float* cond_out, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* length_regulator(S, ylens) alone (InterpolateRegulator.forward, length_regulator.py:117-141) = the prompt-side call of
+ * infer_v2.py:649-652 that turns S_ref into prompt_condition: S [B][M][lr_in_channels]; in_lens / target_lens HOST int32 [B];
+ * cond_out [B][Tg][lr_channels], rows >= target_lens[b] zero.  Workspace: idxtts_s2mel_cond_workspace_bytes(ctx, B, M, Tg). */
+int idxtts_s2mel_regulate(idxtts_ctx* ctx, const float* S, const int* in_lens, const int* target_lens, int B, int M, int Tg, float* cond_out,
+                          void* workspace, size_t workspace_bytes, void* stream);
 /* CFM Euler solve with classifier-free guidance = cfm.inference (flow_matching.py:31-115) with the noise given:
  * mu [B][T][content_dim]; x_lens HOST [B]; prompt [B][in_channels][Tp_max] + prompt_lens HOST [B]; style [B][style_dim];
  * z [B][in_channels][T] (the randn of flow_matching.py:52); t_emb device [n_steps][256] sinusoidal timestep features and

@@ -455,6 +455,14 @@ int idxtts_s2mel_prepare_cond(idxtts_ctx* ctx, const float* latent, const long l
   API_END
 }
 
+int idxtts_s2mel_regulate(idxtts_ctx* ctx, const float* S, const int* in_lens, const int* target_lens, int B, int M, int Tg, float* cond_out,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  API_BEGIN
+  S2MEL_MODEL(ctx);
+  return m->regulate(S, in_lens, target_lens, B, M, Tg, cond_out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+  API_END
+}
+
 size_t idxtts_s2mel_cfm_workspace_bytes(const idxtts_ctx* ctx, int B, int T, int n_steps) {
   if (!ctx || !ctx->finalized || B <= 0 || T <= 0 || n_steps <= 0) return 0;
   auto* m = dynamic_cast<const S2MelModel*>(ctx->model.get());

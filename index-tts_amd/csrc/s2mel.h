@@ -21,6 +21,8 @@ struct WNLayer {
   bool has_res = true;
 };
 
+struct CondBuffers { float *a, *b, *s, *stats; int *idx_code, *idx_row, *idx_interp, *tlen; size_t bytes; };
+
 struct S2MelModel : ModelBase {
   idxtts_s2mel_config cfg;
   std::vector<DiTBlock> blocks;
@@ -48,6 +50,9 @@ struct S2MelModel : ModelBase {
   int estimator(const float* x, const float* prompt, const int* prompt_lens_host, int Tp_max, const int* x_lens_host, const float* t_emb,
                 const float* style, const float* mu, float* out_tm, int B, int T, void* ws, size_t ws_bytes, hipStream_t st);
   size_t cond_workspace_bytes(int B, int M, int Tg) const;
+  int regulate_rows(const float* s_rows, const CondBuffers& w, int B, int M, int Tg, float* cond_out, hipStream_t st);
+  int regulate(const float* S, const int* in_lens_host, const int* target_lens_host, int B, int M, int Tg, float* cond_out, void* ws,
+               size_t ws_bytes, hipStream_t st);
   int prepare_cond(const float* latent, const long long* codes, const int* code_lens_host, const int* target_lens_host, int B, int M,
                    int Tg, float* cond_out, void* ws, size_t ws_bytes, hipStream_t st);
 };

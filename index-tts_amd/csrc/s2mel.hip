@@ -572,7 +572,6 @@ int S2MelModel::estimator(const float* x, const float* prompt, const int* prompt
 }
 
 // ---------------------------------------------------------------------------------------------------------
-struct CondBuffers { float *a, *b, *s, *stats; int *idx_code, *idx_row, *idx_interp, *tlen; size_t bytes; };
 
 static CondBuffers carve_cond(const S2MelModel& m, void* ws, int B, int M, int Tg) {
   const auto& c = m.cfg;
@@ -599,7 +598,7 @@ int S2MelModel::prepare_cond(const float* latent, const long long* codes, const 
   IDX_CHECK(latent && codes && code_lens_host && target_lens_host && cond_out, "null pointer");
   IDX_CHECK(B > 0 && M > 0 && Tg > 0, "shape");
   IDX_CHECK(ws && ws_bytes >= cond_workspace_bytes(B, M, Tg), "workspace too small");
-  const int Hc = cfg.codec_hidden, LC = cfg.lr_channels;
+  const int Hc = cfg.codec_hidden;
   CondBuffers w = carve_cond(*this, ws, B, M, Tg);
   // host-side index tables: code ids, and torch's 'nearest' source row for every target frame
   std::vector<long long> hc((size_t)B * M);
@@ -625,7 +624,7 @@ int S2MelModel::prepare_cond(const float* latent, const long long* codes, const 
   IDX_HIP(hipMemcpyAsync(w.idx_interp, ii.data(), ii.size() * sizeof(int), hipMemcpyHostToDevice, st));
   IDX_HIP(hipMemcpyAsync(w.tlen, tl.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
   IDX_HIP(hipStreamSynchronize(st));
-  const int rowsM = B * M, rowsT = B * Tg;
+  const int rowsM = B * M;
   // gpt_layer: 1280 -> 256 -> 128 -> 1024 (commons.py:413)
   if (gemm(gl[0], latent, cfg.gpt_dim, w.a, gl[0].N, rowsM, st) || gemm(gl[1], w.a, gl[0].N, w.b, gl[1].N, rowsM, st) ||
       gemm(gl[2], w.b, gl[1].N, w.a, Hc, rowsM, st)) return 1;
@@ -635,8 +634,16 @@ int S2MelModel::prepare_cond(const float* latent, const long long* codes, const 
   ga.table[0] = vq_table; ga.idx[0] = w.idx_code;
   ga.table[1] = w.a; ga.idx[1] = w.idx_row;
   if (gather_sum_rows(ga, rowsM, st)) return 1;
+  return regulate_rows(w.s, w, B, M, Tg, cond_out, st);
+}
+
+// InterpolateRegulator.forward on token-major rows s [B*M][lr_in_channels] (length_regulator.py:117-141): content_in_proj, nearest
+// interpolation M_b -> Tg_b through the host-built index table w.idx_interp, 4 x (Conv1d k3 -> GroupNorm(1) -> Mish), Conv1d 1x1, mask
+int S2MelModel::regulate_rows(const float* s_rows, const CondBuffers& w, int B, int M, int Tg, float* cond_out, hipStream_t st) {
+  const int Hc = cfg.codec_hidden, LC = cfg.lr_channels;
+  const int rowsM = B * M, rowsT = B * Tg;
   // content_in_proj, nearest interpolation M_b -> Tg_b (rows beyond Tg_b are zero)
-  if (gemm(lr_in, w.s, Hc, w.a, LC, rowsM, st)) return 1;
+  if (gemm(lr_in, s_rows, Hc, w.a, LC, rowsM, st)) return 1;
   GatherArgs gi;
   gi.out = w.b; gi.ld_out = LC; gi.d = LC; gi.table[0] = w.a; gi.idx[0] = w.idx_interp;
   if (gather_sum_rows(gi, rowsT, st)) return 1;
@@ -651,6 +658,27 @@ int S2MelModel::prepare_cond(const float* latent, const long long* codes, const 
   GemmArgs o;
   o.x = cur; o.ldx = LC; o.y = cond_out; o.ldy = LC; o.M = rowsT; o.seq_len = Tg; o.row_len = w.tlen;    // * mask
   return gemm_forward(lr_out, o, st);
+}
+
+// length_regulator(S, ylens) alone = the prompt-side call of infer_v2.py:649-652 (S_ref -> prompt_condition)
+int S2MelModel::regulate(const float* S, const int* in_lens_host, const int* target_lens_host, int B, int M, int Tg, float* cond_out,
+                         void* ws, size_t ws_bytes, hipStream_t st) {
+  IDX_CHECK(S && in_lens_host && target_lens_host && cond_out, "null pointer");
+  IDX_CHECK(B > 0 && M > 0 && Tg > 0, "shape");
+  IDX_CHECK(ws && ws_bytes >= cond_workspace_bytes(B, M, Tg), "workspace too small");
+  CondBuffers w = carve_cond(*this, ws, B, M, Tg);
+  std::vector<int> ii((size_t)B * Tg, -1), tl(B);
+  for (int b = 0; b < B; ++b) {
+    const int mb = in_lens_host[b], tb = target_lens_host[b];
+    IDX_CHECK(mb > 0 && mb <= M && tb > 0 && tb <= Tg, "in_lens / target_lens out of range");
+    tl[b] = tb;
+    const float scale = (float)mb / (float)tb;      // F.interpolate(mode='nearest'), float32 arithmetic
+    for (int j = 0; j < tb; ++j) ii[(size_t)b * Tg + j] = b * M + std::min((int)std::floor((float)j * scale), mb - 1);
+  }
+  IDX_HIP(hipMemcpyAsync(w.idx_interp, ii.data(), ii.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  IDX_HIP(hipMemcpyAsync(w.tlen, tl.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
+  IDX_HIP(hipStreamSynchronize(st));
+  return regulate_rows(S, w, B, M, Tg, cond_out, st);
 }
 
 }  // namespace idxtts

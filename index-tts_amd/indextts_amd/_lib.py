@@ -25,7 +25,7 @@ SYMBOLS = [
     "idxtts_gpt_beam_workspace_bytes", "idxtts_gpt_generate_beam",
     "idxtts_s2mel_create", "idxtts_s2mel_cond_workspace_bytes", "idxtts_s2mel_prepare_cond",
     "idxtts_s2mel_cfm_workspace_bytes", "idxtts_s2mel_cfm", "idxtts_set_gemm_mode", "idxtts_get_gemm_mode",
-    "idxtts_s2mel_estimator", "idxtts_cond_create", "idxtts_cond_workspace_bytes", "idxtts_cond_forward", "idxtts_emovec_merge",
+    "idxtts_s2mel_estimator", "idxtts_s2mel_regulate", "idxtts_cond_create", "idxtts_cond_workspace_bytes", "idxtts_cond_forward", "idxtts_emovec_merge",
 ]
 
 
@@ -134,6 +134,7 @@ def load() -> ctypes.CDLL:
     lib.idxtts_s2mel_cfm_workspace_bytes.restype = c_size_t
     lib.idxtts_s2mel_cfm.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]
+    lib.idxtts_s2mel_regulate.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.idxtts_s2mel_estimator.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_int, c_int, c_void_p, c_size_t, c_void_p]
     lib.idxtts_cond_create.argtypes = [POINTER(CondConfigC), POINTER(c_void_p)]

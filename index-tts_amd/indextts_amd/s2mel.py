@@ -101,6 +101,24 @@ class S2Mel:
                                                  _lib.current_stream()))
         return cond, tl.to(self.device)
 
+    def length_regulator(self, x: torch.Tensor, ylens, n_quantizers=None, f0=None) -> tuple:
+        """`models['length_regulator'](S, ylens=..., n_quantizers=3, f0=None)` (length_regulator.py:90-141): x [B,M,1024], ylens [B]
+        -> (cond [B, max(ylens), 512], ylens): the prompt-side call of infer_v2.py:649-652 (S_ref -> prompt_condition)."""
+        if f0 is not None:
+            raise NotImplementedError("f0 conditioning is disabled in IndexTTS-2 (config.yaml:76)")
+        lib = _lib.load()
+        xs = x.to(self.device, torch.float32).contiguous()
+        B, M, _ = xs.shape
+        tl = torch.as_tensor(ylens).detach().cpu().long().reshape(-1)
+        Tg = int(tl.max())
+        il32 = np.full(B, M, np.int32)
+        tl32 = np.ascontiguousarray(tl.numpy(), dtype=np.int32)
+        cond = torch.empty(B, Tg, self.cfg.lr_channels, device=self.device, dtype=torch.float32)
+        ws = self._workspace(int(lib.idxtts_s2mel_cond_workspace_bytes(self._h, B, M, Tg)))
+        _lib.check(lib.idxtts_s2mel_regulate(self._h, _lib.ptr(xs), il32.ctypes.data_as(c_void_p), tl32.ctypes.data_as(c_void_p), B, M, Tg,
+                                             _lib.ptr(cond), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+        return cond, tl.to(self.device)
+
     def cfm_inference(self, mu: torch.Tensor, x_lens, prompt: torch.Tensor, style: torch.Tensor, f0=None, n_timesteps: int = 20,
                       temperature: float = 1.0, inference_cfg_rate: float = 0.7, z: torch.Tensor = None, prompt_lens=None):
         """mu [B,T,512], x_lens [B], prompt [B,80,Tp], style [B,192] -> mel [B,80,T] (flow_matching.py:31-55).

@@ -59,6 +59,17 @@ def test_condition_path_vs_reference_golden(device, golden_dir):
     assert (got[1] - torch.from_numpy(g["cond_b"])[0]).abs().max().item() <= 5e-5
 
 
+def test_length_regulator_vs_reference_golden(device, golden_dir):
+    """`length_regulator(S, ylens)` alone (the S_ref -> prompt_condition call, infer_v2.py:649-652) against the reference module's
+    own outputs for two lengths."""
+    g, cfg, w, sm = _tiny(golden_dir, device)
+    for tag, M in (("a", 9), ("b", 20)):
+        S = torch.from_numpy(synth.uniform(f"golden/s2mel/S_{tag}", (1, M, cfg.lr_in_channels), 1.0))
+        ylens = (torch.LongTensor([M]) * 1.72).long()
+        cond, _ = sm.length_regulator(S, ylens, n_quantizers=3, f0=None)
+        np.testing.assert_allclose(cond.cpu().numpy(), g[f"lr_{tag}"], rtol=0, atol=5e-5)
+
+
 def test_gpt_layer_and_vq2emb_vs_reference_golden(device, golden_dir):
     """`gpt_layer(latent)` and `vq2emb(codes)` fixtures of the reference: the HIP condition path is linear in each up to the
     length regulator, so they are checked through the one place their sum is visible -- content_in_proj has no nonlinearity
