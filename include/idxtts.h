@@ -31,15 +31,18 @@ extern "C" {
 typedef struct idxtts_ctx idxtts_ctx;
 
 #define IDXTTS_DTYPE_F32 0
+#define IDXTTS_DTYPE_F16 1
+#define IDXTTS_DTYPE_BF16 2
 
 int idxtts_version(void);
 /* Last error message of the calling thread ("" if none). */
 const char* idxtts_last_error(void);
 
 /* ---- fused anti-aliased SnakeBeta activation (reference: fwd_cuda, .cu:212-246) -------------------
- * out/in: [B][C][T]; up_filter/down_filter: 12 taps; log_alpha/log_beta: [C] (log-scale, exp'd in-kernel,
- * .cu:86-89).  T == 0 is a no-op (.cu:193).  out must not alias in.  dtype must be IDXTTS_DTYPE_F32. */
-int idxtts_aa_act_fwd(float* out, const float* in, const float* up_filter, const float* down_filter,
+ * out/in: [B][C][T] of element type `dtype` (IDXTTS_DTYPE_F32 / F16 / BF16: the dispatch of .cu:232-244; 16-bit inputs are
+ * widened on load, the arithmetic is float32 throughout, the result is rounded once on store); up_filter/down_filter: 12 float32
+ * taps; log_alpha/log_beta: float32 [C] (log-scale, exp'd in-kernel, .cu:86-89).  T == 0 is a no-op (.cu:193).  out must not alias in. */
+int idxtts_aa_act_fwd(void* out, const void* in, const float* up_filter, const float* down_filter,
                       const float* log_alpha, const float* log_beta, int B, int C, int T, int dtype,
                       void* stream);
 

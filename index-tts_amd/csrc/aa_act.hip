@@ -30,9 +30,29 @@ constexpr int AA_TPW = 4;       // consecutive tiles per workgroup (the next til
 constexpr int AA_XH = 8;        // x halo each side (>= 6 needed, 8 keeps float4 alignment)
 constexpr int AA_VH = 4;        // polyphase halo each side (>= 3 needed)
 
+// element type of x / y: 0 float32, 1 float16, 2 bfloat16 (the reference kernel dispatches on the input dtype the same way,
+// anti_alias_activation_cuda.cu:232-244); filters, alpha and beta are float32 and all arithmetic is float32 -- 16-bit inputs are
+// widened on load and the result is rounded once on store
+template <int DT> struct AAIo;
+template <> struct AAIo<0> {
+  typedef float T;
+  static __device__ __forceinline__ float ld(const void* p, size_t i) { return static_cast<const float*>(p)[i]; }
+  static __device__ __forceinline__ void st(void* p, size_t i, float v) { static_cast<float*>(p)[i] = v; }
+};
+template <> struct AAIo<1> {
+  typedef _Float16 T;
+  static __device__ __forceinline__ float ld(const void* p, size_t i) { return (float)static_cast<const _Float16*>(p)[i]; }
+  static __device__ __forceinline__ void st(void* p, size_t i, float v) { static_cast<_Float16*>(p)[i] = (_Float16)v; }
+};
+template <> struct AAIo<2> {
+  typedef __bf16 T;
+  static __device__ __forceinline__ float ld(const void* p, size_t i) { return (float)static_cast<const __bf16*>(p)[i]; }
+  static __device__ __forceinline__ void st(void* p, size_t i, float v) { static_cast<__bf16*>(p)[i] = (__bf16)v; }
+};
+
 struct AAParams {
-  const float* x;
-  float* y;
+  const void* x;
+  void* y;
   const float* up_f;     // [12]
   const float* down_f;   // [12]
   const float* log_alpha;  // [C]
@@ -66,8 +86,9 @@ __device__ __forceinline__ float snake(float u, float a, float inv_b) {
 
 // RAGGED = false is the original single-length kernel (the hot path of equal-length batches); RAGGED = true adds the per-row
 // length handling of AAParams::lens.
-template <bool RAGGED>
+template <bool RAGGED, int DT>
 __global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
+  typedef AAIo<DT> IO;
   __shared__ __attribute__((aligned(16))) float xs[AA_TILE + 2 * AA_XH];
   __shared__ __attribute__((aligned(16))) float ve[AA_TILE + 2 * AA_VH];
   __shared__ __attribute__((aligned(16))) float vo[AA_TILE + 2 * AA_VH];
@@ -77,7 +98,6 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
   const int Tstride = p.T;                                                     // row stride of the padded tensor
   const int T = RAGGED ? min(p.T, p.lens[b] * p.len_mul) : p.T;               // this row's own length
   const size_t row = ((size_t)b * p.C + c) * Tstride;
-  const float* __restrict__ x = p.x + row;
 
   // filters and per-channel constants (wave-uniform -> scalar registers)
   float fe[6], fo[6], ge[6], go[6];
@@ -102,7 +122,7 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
       const int i = tid + 256 * k;
       int t = t0n - AA_XH + i;
       t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
-      xr[k] = (i < AA_TILE + 2 * AA_XH && T > 0) ? x[t] : 0.0f;
+      xr[k] = (i < AA_TILE + 2 * AA_XH && T > 0) ? IO::ld(p.x, row + t) : 0.0f;
     }
   };
   const int tile_first = blockIdx.x * AA_TPW;
@@ -111,8 +131,7 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
   const int t0 = (tile_first + tt) * AA_TILE;
   if (t0 >= Tstride) break;
   if (RAGGED && t0 >= T) {       // tile entirely in the padding of a shorter row: zeros (and so are all later tiles)
-    float* __restrict__ yz = p.y + row;
-    for (int i = tid; i < AA_TILE && t0 + i < Tstride; i += 256) yz[t0 + i] = 0.0f;
+    for (int i = tid; i < AA_TILE && t0 + i < Tstride; i += 256) IO::st(p.y, row + t0 + i, 0.0f);
     continue;
   }
   // ---- phase 1: x tile with replicate (clamped) halo (requested one tile ago) ----
@@ -182,10 +201,9 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
   const int t = t0 + 4 * tid;
   if (t >= Tstride) continue;    // (no barrier is skipped: the next tile of this row starts beyond Tstride too -> break above)
   if (RAGGED && t >= T) {        // padding of a shorter row inside a partly valid tile
-    float* __restrict__ yz = p.y + row;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (t + i < Tstride) yz[t + i] = 0.0f;
+      if (t + i < Tstride) IO::st(p.y, row + t + i, 0.0f);
     continue;                    // the next tile lies wholly in the padding: no barrier there either
   }
   float ew[12], ow[12];
@@ -214,19 +232,21 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
     }
     out[i] = acc;
   }
-  float* __restrict__ y = p.y + row;
-  if ((Tstride & 3) == 0 && (!RAGGED || t + 3 < T)) {
-    *reinterpret_cast<f32x4*>(&y[t]) = f32x4{out[0], out[1], out[2], out[3]};
+  if (DT == 0 && (Tstride & 3) == 0 && (!RAGGED || t + 3 < T)) {
+    *reinterpret_cast<f32x4*>(static_cast<float*>(p.y) + row + t) = f32x4{out[0], out[1], out[2], out[3]};
+  } else if (DT != 0 && (Tstride & 3) == 0 && (!RAGGED || t + 3 < T)) {
+    typedef typename IO::T h4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<h4*>(static_cast<typename IO::T*>(p.y) + row + t) = h4{(typename IO::T)out[0], (typename IO::T)out[1], (typename IO::T)out[2], (typename IO::T)out[3]};
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (t + i < Tstride) y[t + i] = t + i < T ? out[i] : 0.0f;
+      if (t + i < Tstride) IO::st(p.y, row + t + i, t + i < T ? out[i] : 0.0f);
   }
   }   // tiles of this workgroup
 }
 
-int aa_act_forward(float* y, const float* x, const float* up_f, const float* down_f, const float* log_alpha,
-                   const float* log_beta, int B, int C, int T, hipStream_t stream, const int* lens, int len_mul) {
+int aa_act_forward(void* y, const void* x, const float* up_f, const float* down_f, const float* log_alpha,
+                   const float* log_beta, int B, int C, int T, hipStream_t stream, const int* lens, int len_mul, int dtype) {
   if (B == 0 || C == 0 || T == 0) return 0;   // reference: seq_len == 0 -> no-op (.cu:193)
   IDX_CHECK(y && x && up_f && down_f && log_alpha && log_beta, "null pointer");
   IDX_CHECK(y != x, "aa_act is not in-place safe (tile halos)");
@@ -234,8 +254,15 @@ int aa_act_forward(float* y, const float* x, const float* up_f, const float* dow
   AAParams p{x, y, up_f, down_f, log_alpha, log_beta, C, T, lens, len_mul};
   dim3 grid(cdiv(cdiv(T, AA_TILE), AA_TPW), C, B);
   ProfScope prof(PROF_AA_ACT, stream, 0.0, 8.0 * B * C * (double)T);   // one read + one write per element
-  if (lens) hipLaunchKernelGGL(aa_act_kernel<true>, grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL(aa_act_kernel<false>, grid, dim3(256), 0, stream, p);
+  IDX_CHECK(dtype >= 0 && dtype <= 2, "dtype: 0 float32, 1 float16, 2 bfloat16");
+  if (dtype == 0) {
+    if (lens) hipLaunchKernelGGL((aa_act_kernel<true, 0>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((aa_act_kernel<false, 0>), grid, dim3(256), 0, stream, p);
+  } else {
+    IDX_CHECK(!lens, "ragged batches are float32 (the vocoder's own tensors)");
+    if (dtype == 1) hipLaunchKernelGGL((aa_act_kernel<false, 1>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((aa_act_kernel<false, 2>), grid, dim3(256), 0, stream, p);
+  }
   IDX_LAUNCH_CHECK();
   return 0;
 }

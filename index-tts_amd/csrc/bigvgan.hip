@@ -16,8 +16,8 @@
 
 namespace idxtts {
 
-int aa_act_forward(float* y, const float* x, const float* up_f, const float* down_f, const float* log_alpha,
-                   const float* log_beta, int B, int C, int T, hipStream_t stream, const int* lens = nullptr, int len_mul = 1);
+int aa_act_forward(void* y, const void* x, const float* up_f, const float* down_f, const float* log_alpha,
+                   const float* log_beta, int B, int C, int T, hipStream_t stream, const int* lens = nullptr, int len_mul = 1, int dtype = 0);
 int conv_post_forward(float* y, const float* x, const float* w, int B, int C, int T, int clamp, hipStream_t stream);
 
 // kaiser-sinc low-pass, cutoff 0.25, half-width 0.3, 12 taps (filter.py:30-62), in double.

@@ -21,8 +21,8 @@ int fail(const char* file, int line, const std::string& msg) {
   return 1;
 }
 
-int aa_act_forward(float* y, const float* x, const float* up_f, const float* down_f, const float* log_alpha,
-                   const float* log_beta, int B, int C, int T, hipStream_t stream, const int* lens = nullptr, int len_mul = 1);
+int aa_act_forward(void* y, const void* x, const float* up_f, const float* down_f, const float* log_alpha,
+                   const float* log_beta, int B, int C, int T, hipStream_t stream, const int* lens = nullptr, int len_mul = 1, int dtype = 0);
 
 }  // namespace idxtts
 
@@ -51,12 +51,12 @@ int idxtts_version(void) { return 100; }
 
 const char* idxtts_last_error(void) { return g_last_error.c_str(); }
 
-int idxtts_aa_act_fwd(float* out, const float* in, const float* up_filter, const float* down_filter,
+int idxtts_aa_act_fwd(void* out, const void* in, const float* up_filter, const float* down_filter,
                       const float* log_alpha, const float* log_beta, int B, int C, int T, int dtype, void* stream) {
   API_BEGIN
-  IDX_CHECK(dtype == IDXTTS_DTYPE_F32, "only float32 is implemented");
+  IDX_CHECK(dtype == IDXTTS_DTYPE_F32 || dtype == IDXTTS_DTYPE_F16 || dtype == IDXTTS_DTYPE_BF16, "dtype must be IDXTTS_DTYPE_F32 / F16 / BF16");
   IDX_CHECK(B >= 0 && C >= 0 && T >= 0, "negative shape");
-  return aa_act_forward(out, in, up_filter, down_filter, log_alpha, log_beta, B, C, T, static_cast<hipStream_t>(stream));
+  return aa_act_forward(out, in, up_filter, down_filter, log_alpha, log_beta, B, C, T, static_cast<hipStream_t>(stream), nullptr, 1, dtype);
   API_END
 }
 

@@ -42,21 +42,31 @@ def _require_gpu_f32(t: torch.Tensor, name: str) -> torch.Tensor:
 
 def anti_alias_activation_forward(inputs: torch.Tensor, up_ftr: torch.Tensor, down_ftr: torch.Tensor,
                                   alpha: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
-    """Fused up(x2) -> SnakeBeta(log-scale alpha, beta) -> down(x2).  inputs [B,C,T] -> new tensor [B,C,T]."""
+    """Fused up(x2) -> SnakeBeta(log-scale alpha, beta) -> down(x2).  inputs [B,C,T] float32 / float16 / bfloat16 (the reference
+    kernel's dtype dispatch, anti_alias_activation_cuda.cu:232-244) -> new tensor [B,C,T] of the same dtype; filters and alpha / beta
+    are taken as float32 and the arithmetic is float32."""
     lib = _lib.load()
-    x = _require_gpu_f32(inputs, "inputs")
+    dt = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}.get(inputs.dtype)
+    if dt is None:
+        raise TypeError(f"inputs: float32, float16 or bfloat16, got {inputs.dtype}")
+    if dt == 0:
+        x = _require_gpu_f32(inputs, "inputs")
+    else:
+        if inputs.device.type != "cuda":
+            raise RuntimeError("inputs: expected a ROCm GPU tensor; the HIP path has no CPU fallback")
+        x = inputs.contiguous()
     if x.dim() != 3:
         raise ValueError("inputs must be [B, C, T]")
     B, C, T = x.shape
-    upf = _require_gpu_f32(up_ftr.reshape(-1), "up_ftr")
-    dnf = _require_gpu_f32(down_ftr.reshape(-1), "down_ftr")
-    a = _require_gpu_f32(alpha.reshape(-1), "alpha")
-    b = _require_gpu_f32(beta.reshape(-1), "beta")
+    upf = _require_gpu_f32(up_ftr.reshape(-1).float(), "up_ftr")
+    dnf = _require_gpu_f32(down_ftr.reshape(-1).float(), "down_ftr")
+    a = _require_gpu_f32(alpha.reshape(-1).float(), "alpha")
+    b = _require_gpu_f32(beta.reshape(-1).float(), "beta")
     if upf.numel() != 12 or dnf.numel() != 12 or a.numel() != C or b.numel() != C:
         raise ValueError("filters must have 12 taps and alpha/beta one value per channel")
     out = torch.empty_like(x)   # freshly allocated with the input's options, like the reference (.cu:220-223)
     _lib.check(lib.idxtts_aa_act_fwd(_lib.ptr(out), _lib.ptr(x), _lib.ptr(upf), _lib.ptr(dnf), _lib.ptr(a),
-                                     _lib.ptr(b), B, C, T, 0, _lib.current_stream()))
+                                     _lib.ptr(b), B, C, T, dt, _lib.current_stream()))
     return out
 
 

@@ -57,6 +57,29 @@ def test_aa_act_matches_reference_golden(device, golden_dir):
         np.testing.assert_allclose(y.cpu().numpy(), g[f"act_{tag}_y"], rtol=0, atol=ACT_ATOL)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_aa_act_half_precision_io(device, dtype):
+    """fp16 / bf16 tensors in and out (the reference kernel's dtype dispatch, anti_alias_activation_cuda.cu:232-244): 16-bit
+    inputs are widened on load, the arithmetic is fp32, the result is rounded ONCE -- i.e. exactly the fp32 result of the same
+    (rounded) input, rounded to the dtype; and within a few ulps of the reference's torch path run in that dtype."""
+    from indextts_amd.vocoder import anti_alias_activation_forward
+    from oracle import vocoder as ov
+    f = _filt(device)
+    for (B, C, T) in [(2, 5, 300), (1, 3, 1027), (1, 2, 1)]:
+        la = torch.from_numpy(synth.uniform(f"t/act16/a/{C}", (C,), 0.8))
+        lb = torch.from_numpy(synth.uniform(f"t/act16/b/{C}", (C,), 0.8, offset=0.2))
+        x = torch.from_numpy(synth.uniform(f"t/act16/x/{B}{C}{T}", (B, C, T), 3.0)).to(dtype)
+        y = anti_alias_activation_forward(x.to(device), f, f, la.to(device), lb.to(device))
+        assert y.dtype == dtype and y.shape == x.shape
+        y32 = anti_alias_activation_forward(x.float().to(device), f, f, la.to(device), lb.to(device))
+        assert torch.equal(y.cpu(), y32.cpu().to(dtype))                              # one rounding, at the store
+        ref = ov.activation1d(x.float(), la, lb)                                       # CPU oracle on the rounded input
+        ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+        assert ((y.cpu().float() - ref).abs() <= ulp * ref.abs().clamp_min(1.0)).all()
+    with pytest.raises(TypeError):
+        anti_alias_activation_forward(torch.zeros(1, 1, 4, dtype=torch.float64, device=device), f, f, la[:1].to(device), lb[:1].to(device))
+
+
 @pytest.mark.parametrize("shape", [(1, 1, 1), (1, 3, 2), (2, 5, 3), (1, 2, 5), (1, 4, 1023), (1, 3, 1024), (2, 3, 1025),
                                    (1, 2, 1030), (1, 24, 2048 + 7), (3, 7, 4096), (1, 1, 5000)])
 def test_aa_act_vs_oracle_ragged(device, shape):
