@@ -433,8 +433,12 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
   }
 
   // ---- decode ----
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
+  struct GraphGuard {      // released on every return path (error paths after the capture included)
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    ~GraphGuard() { if (exec) (void)hipGraphExecDestroy(exec); if (graph) (void)hipGraphDestroy(graph); }
+  } gg;
+  hipGraph_t& graph = gg.graph;
+  hipGraphExec_t& exec = gg.exec;
   const bool graph_ok = use_graph && !logits_out && !prof_enabled();
   int n_first = 1;
   if (graph_ok && max_new > 2) {
@@ -466,8 +470,6 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
       if (all) break;
     }
   }
-  if (exec) (void)hipGraphExecDestroy(exec);
-  if (graph) (void)hipGraphDestroy(graph);
   // exact HF length: generation stops at the first step after which every row has emitted the stop token
   std::vector<long long> hc((size_t)B * max_new);
   IDX_HIP(hipMemcpyAsync(hc.data(), codes, hc.size() * sizeof(long long), hipMemcpyDeviceToHost, st));

@@ -362,14 +362,32 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
     pr.taps = c.wn_kernel; pr.seq_len = T;
     chain_wn = chain_wn && gemm_uses_planes(m.wn[0].in_gate, pr);
   }
-  float* const hn_f = chain ? nullptr : w.hn;
   void* const hn_p = chain ? w.hn_p : nullptr;
-  auto ada = [&](const float* x, const float* g, int mod_idx) {
+  // The solver needs the estimate only on the frames t >= tail_t0 (see below): the post-transformer part and, in the LAST block,
+  // everything after the K/V projection run on those frames alone, compacted to [N2][Tt] rows.
+  const int t0 = w.tail_t0, Tt = T - t0, Mt = N2 * Tt;
+  bool chain_t = chain, chain_wn_t = chain_wn;
+  if (t0 > 0) {
+    GemmArgs pr;
+    pr.M = Mt;
+    const LinearWeights* used[] = {&m.blocks[0].wo, &m.blocks[0].w13, &m.blocks[0].w2, &m.skiplin_a, &m.final_lin, &m.wn[0].skip};
+    for (const LinearWeights* lw : used) chain_t = chain_t && gemm_uses_planes(*lw, pr);
+    chain_wn_t = chain_t && chain_wn && gemm_uses_planes(m.skiplin_b, pr) && gemm_uses_planes(m.conv1, pr) && gemm_uses_planes(m.res_proj, pr) &&
+                 gemm_uses_planes(m.wn[0].res, pr);
+    pr.taps = c.wn_kernel; pr.seq_len = Tt;
+    chain_wn_t = chain_wn_t && gemm_uses_planes(m.wn[0].in_gate, pr);
+  }
+  float* const hnt_f = chain_t ? nullptr : w.hn;
+  void* const hnt_p = chain_t ? w.hn_p : nullptr;
+  auto ada_rows = [&](const float* x, const float* g, int mod_idx, int rows, bool planes) {
     RowsNormArgs n;
-    n.x_in = x; n.ld_in = D; n.y = hn_f; n.y_planes = hn_p; n.ld_y = D; n.M = M; n.d = D; n.mode = NORM_ADA_RMS; n.eps = c.norm_eps; n.g1 = g;
+    n.x_in = x; n.ld_in = D; n.y = planes ? nullptr : w.hn; n.y_planes = planes ? w.hn_p : nullptr; n.ld_y = D; n.M = rows; n.d = D;
+    n.mode = NORM_ADA_RMS; n.eps = c.norm_eps; n.g1 = g;
     n.mod_a = mods + (size_t)mod_idx * 2 * D; n.mod_b = n.mod_a + D; n.ld_mod = 0; n.rows_per_batch = 0;
     return rows_norm_forward(n, st);
   };
+  auto ada = [&](const float* x, const float* g, int mod_idx) { return ada_rows(x, g, mod_idx, M, chain); };
+  bool h_compact = false;      // h already holds only the tail rows (the last block produced it that way)
   if (gemm(m.merge, w.x_in, Win, w.ha, D, M, st)) return 1;
   float* h = w.ha;
   int pushed = 0;
@@ -398,6 +416,22 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
     a.q_ts = a.k_ts = a.v_ts = 3 * D; a.o_ts = D;
     a.B = N2; a.H = c.num_heads; a.Sq = T; a.Sk = T; a.causal = 0; a.kend = w.lens2; a.scale = 0.125f;
     a.split_bf16 = get_gemm_mode() == GEMM_BF16X3;
+    if (i == depth - 1 && t0 > 0 && i >= half) {
+      // last block: its keys / values cover every frame, but only the tail frames' queries, attention output, projection and
+      // feed-forward are ever used (nothing attends to this block's output): Mt rows instead of M from here on
+      a.q = w.qkv + (size_t)t0 * 3 * D; a.Sq = Tt; a.o_bs = (long)Tt * D;
+      if (chain_t) { a.o = nullptr; a.o_planes = w.att_p; }
+      if (flash_attn_forward(a, st)) return 1;
+      if (gather_tail_rows(w.xres, D, h, D, D, N2, T, t0, st)) return 1;                       // residual rows (xres is free here)
+      if (gemm(B.wo, w.att, D, w.hmid, D, Mt, st, ACT_NONE, w.xres, D, chain_t ? w.att_p : nullptr)) return 1;
+      if (ada_rows(w.hmid, B.ffn_g, 2 * i + 1, Mt, chain_t)) return 1;
+      if (gemm(B.w13, w.hn, D, chain_t ? nullptr : w.ff, m.ffn, Mt, st, ACT_SWIGLU, nullptr, 0, hnt_p, chain_t ? w.ff_p : nullptr)) return 1;
+      float* dst = (h == w.ha) ? w.hb : w.ha;
+      if (gemm(B.w2, w.ff, m.ffn, dst, D, Mt, st, ACT_NONE, w.hmid, D, chain_t ? w.ff_p : nullptr, nullptr)) return 1;
+      h = dst;
+      h_compact = true;
+      break;
+    }
     if (chain) { a.o = nullptr; a.o_planes = w.att_p; }
     if (flash_attn_forward(a, st)) return 1;
     if (gemm(B.wo, w.att, D, w.hmid, D, M, st, ACT_NONE, h, D, chain ? w.att_p : nullptr)) return 1;           // h + attention(...)
@@ -415,29 +449,19 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
   // only the frames t >= tail_t0 = prompt_len - halo are evaluated -- the prompt is 44 % of the frames at configs[2] -- on rows
   // compacted to [N2][T - tail_t0].  The frames t >= prompt_len come out bit-identical: the reflect padding at the cut only reaches
   // the halo.  tail_t0 = 0 (the stand-alone estimator entry point): every frame.
-  const int t0 = w.tail_t0, Tt = T - t0, Mt = N2 * Tt;
   const float* ht = h;
   const float* xin_t = w.x_in;
   int ld_xin = Win;
   const int* lens_t = w.lens2;
   if (t0 > 0) {
-    float* hc = (h == w.ha) ? w.hb : w.ha;
-    if (gather_tail_rows(hc, D, h, D, D, N2, T, t0, st)) return 1;
+    if (!h_compact) {
+      float* hc = (h == w.ha) ? w.hb : w.ha;
+      if (gather_tail_rows(hc, D, h, D, D, N2, T, t0, st)) return 1;
+      ht = hc;
+    }
     if (gather_tail_rows(w.qkv, C, w.x_in, Win, C, N2, T, t0, st)) return 1;      // the x columns of x_in (qkv is free here)
-    ht = hc; xin_t = w.qkv; ld_xin = C; lens_t = w.lens2t;
+    xin_t = w.qkv; ld_xin = C; lens_t = w.lens2t;
   }
-  bool chain_t = chain, chain_wn_t = chain_wn;
-  if (t0 > 0) {
-    GemmArgs pr;
-    pr.M = Mt;
-    chain_t = chain && gemm_uses_planes(m.skiplin_a, pr) && gemm_uses_planes(m.final_lin, pr) && gemm_uses_planes(m.wn[0].skip, pr);
-    chain_wn_t = chain_t && chain_wn && gemm_uses_planes(m.skiplin_b, pr) && gemm_uses_planes(m.conv1, pr) && gemm_uses_planes(m.res_proj, pr) &&
-                 gemm_uses_planes(m.wn[0].res, pr);
-    pr.taps = c.wn_kernel; pr.seq_len = Tt;
-    chain_wn_t = chain_wn_t && gemm_uses_planes(m.wn[0].in_gate, pr);
-  }
-  float* const hnt_f = chain_t ? nullptr : w.hn;
-  void* const hnt_p = chain_t ? w.hn_p : nullptr;
   {
     RowsNormArgs n;
     n.x_in = ht; n.ld_in = D; n.y = hnt_f; n.y_planes = hnt_p; n.ld_y = D; n.M = Mt; n.d = D; n.mode = NORM_ADA_RMS; n.eps = c.norm_eps; n.g1 = m.final_g;
