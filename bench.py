@@ -175,28 +175,17 @@ def build_pipeline(args, world, rank, dev):
             gather_waveforms(wavs, dst=0, same_count=True)
         return wavs[0]
 
-    # Two-stage software pipeline ACROSS steps (default): the decode of batch k + 1 (latency-bound: 125 small launches per
-    # token, MFMA units idle) runs on the main thread's stream while a worker thread runs s2mel + vocoder of batch k
-    # (MFMA-bound) on a second stream; every step's whole work stays inside the timed region (flush() joins the last batch
-    # before the closing barrier), the results are those of the sequential loop, and all collectives stay on the main thread in
-    # a fixed order.  --no-overlap runs the steps strictly one after the other.
-    import concurrent.futures
-    pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
-    # The decode's many small launches get the high-priority queue, so they are dispatched ahead of the queued workgroups of
-    # the s2mel GEMMs whenever a CU frees up.  (CU-masked streams, hipExtStreamCreateWithCUMask, are accepted but have no
-    # effect for an unprivileged user on this pool: a masked stream runs an 8192^3 GEMM exactly as fast as a plain one.)
-    lo_pri, hi_pri = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
-    s_gpt_full = s_gpt_part = torch.cuda.Stream(device=dev, priority=hi_pri)
-    s_ac_full = s_ac_part = torch.cuda.Stream(device=dev, priority=lo_pri)
+    # Software pipeline ACROSS steps (default; indextts_amd/serving.py): `--decode-lanes` decode chains of consecutive batches in
+    # flight at once -- latency-bound chains of 125 small launches per token that leave most CUs idle and interleave almost for
+    # free, each on its own stream and host thread -- and ONE s2mel + vocoder stage (MFMA-bound) at a time behind them on a further
+    # stream.  Every step's whole work stays inside the timed region (flush() joins every batch before the closing barrier), each
+    # batch is computed exactly as the sequential loop computes it (checked after the run: `outputs_equal_sequential`), and all
+    # collectives stay on the main thread in a fixed order.  --no-overlap runs the steps strictly one after the other.
+    # (CU-masked streams, hipExtStreamCreateWithCUMask, are accepted but have no effect for an unprivileged user on this pool.)
+    from indextts_amd.serving import BatchPipeline
+    lanes = max(1, args.decode_lanes)
+    pipe = None if args.no_overlap else BatchPipeline(tts, decode_lanes=lanes)
     pending = []
-
-    def acoustic_job(st, ev, stream):
-        torch.cuda.set_device(dev)
-        with torch.cuda.stream(stream):
-            stream.wait_event(ev)
-            wavs = tts.acoustic_stage(st, noise=noise)
-            stream.synchronize()        # the state's tensors may be released once this returns
-        return wavs
 
     def retire(fut):
         wavs = fut.result()
@@ -206,20 +195,17 @@ def build_pipeline(args, world, rank, dev):
 
     def step_pipelined(last=False):
         c = broadcast_conditioning(cond_dev if rank == 0 else None, shapes, dev) if world > 1 else cond_dev
-        sg = s_gpt_part if pending else s_gpt_full
-        sg.wait_stream(torch.cuda.current_stream())         # the broadcast conditioning bundle is produced on the caller's stream
-        with torch.cuda.stream(sg):
-            st = tts.gpt_stage(text, c, max_mel_tokens=M)
-            ev = torch.cuda.Event()
-            ev.record(sg)
-        out = retire(pending.pop(0)) if pending else None
-        pending.append(pool.submit(acoustic_job, st, ev, s_ac_full if last else s_ac_part))
+        out = retire(pending.pop(0)) if len(pending) > lanes else None       # at most lanes + 1 batches in flight
+        pending.append(pipe.submit(text, c, max_mel_tokens=M, noise=noise))
         return out
+
+    flushed = []
 
     def flush():
         out = None
         while pending:
             out = retire(pending.pop(0))
+            flushed.append(out)
         return out
 
     step = step_sequential if args.no_overlap else step_pipelined
@@ -266,8 +252,11 @@ def build_pipeline(args, world, rank, dev):
             "gpt_weights": args.gpt_weights,
             "batch_per_gpu": B, "text_tokens": L, "codes": M, "prompt_frames": Tp, "diffusion_steps": cfg.diffusion_steps}
     desc["step_overlap"] = ("none" if args.no_overlap else
-                            "two-stage pipeline across steps: decode of batch k+1 overlaps s2mel+vocoder of batch k (two streams, one worker thread)")
+                            f"software pipeline across steps: {lanes} decode chain(s) of consecutive batches in flight (one stream + host thread "
+                            "each), one s2mel+vocoder stage at a time behind them on its own stream; every batch inside the timed region")
     step.flush = (lambda: None) if args.no_overlap else flush
+    step.reference = lambda: tts.synthesize_batch(text, cond_dev, max_mel_tokens=M, noise=noise)[0]
+    step.flushed = flushed
     return step, profiled, cpu_leg, stage_times, audio_s, desc
 
 
@@ -310,9 +299,11 @@ def main() -> int:
     ap.add_argument("--cpu-codes", type=int, default=96, help="codes of the bounded CPU-baseline utterance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--decode-lanes", type=int, default=3,
+                    help="pipeline workload: decode chains of consecutive batches in flight at once (each on its own stream and host thread)")
     ap.add_argument("--no-overlap", action="store_true",
-                    help="pipeline workload: run the K steps strictly one after the other (default: the decode of step k+1 overlaps "
-                         "the s2mel + vocoder stages of step k on a second stream)")
+                    help="pipeline workload: run the K steps strictly one after the other (default: the decode chains of the next "
+                         "--decode-lanes steps overlap the s2mel + vocoder stage of the current one)")
     ap.add_argument("--gpt-weights", default=None, choices=["f32", "bf16", "fp8"],
                     help="storage of the GPT linear weights: bf16 (default for the pipeline workload: what BASELINE configs[2] names), "
                          "fp8-e4m3 with a power-of-two scale per output channel (default for longform = configs[4]), or f32 (the reference's "
@@ -375,11 +366,13 @@ def main() -> int:
         log(f"[bench] rank {rank}: warmup {i + 1}/{args.warmup} done")
     barrier()
     t_start = time.perf_counter()
-    out = None
+    out, outs = None, []
     for k in range(args.steps):
         o = step(last=(k == args.steps - 1)) if args.workload == "pipeline" else step()
         out = o if o is not None else out
-    o = flush()                     # the last batch's s2mel + vocoder: inside the timed region
+        if o is not None:
+            outs.append(o)
+    o = flush()                     # the batches still in flight: inside the timed region
     out = o if o is not None else out
     barrier()
     elapsed = time.perf_counter() - t_start
@@ -389,6 +382,13 @@ def main() -> int:
         elapsed = float(tmax.item())
     assert torch.isfinite(out).all()
     log(f"[bench] rank {rank}: {args.steps} steps in {elapsed:.3f}s")
+    equal_seq = None
+    if hasattr(step, "reference"):      # every step has the same inputs: each retired batch must equal the sequential call bit for bit
+        ref = step.reference()
+        outs = outs + list(getattr(step, "flushed", []))[-args.steps:] + [out]
+        equal_seq = bool(all(torch.equal(o, ref) for o in outs))
+        log(f"[bench] rank {rank}: {len(outs)} pipelined outputs equal the sequential synthesize_batch bit for bit: {equal_seq}")
+        assert equal_seq, "a pipelined batch differs from the sequential result"
 
     roofline = stages = None
     if rank == 0 and not args.no_roofline:
@@ -442,6 +442,8 @@ def main() -> int:
                      "timed_region": "inputs (token ids, conditioning, CFM noise) already resident in HBM; waveforms stay on the device "
                                      "(rank 0 after the gather): H2D of the inputs and the final wav.cpu() of infer_v2.py:892 are outside "
                                      "(14 MB / step at 16 utterances, < 0.4 ms over PCIe)"})
+        if equal_seq is not None:
+            cfgd["outputs_equal_sequential"] = equal_seq
         if world > 1 and dist.get_backend() == "nccl":
             cfgd["rccl_ranks"] = dist.get_world_size()
         if world >= 8 and cfgd.get("batch_per_gpu") == 32 and not longform:

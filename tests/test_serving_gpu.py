@@ -1,0 +1,107 @@
+"""GPU: the batch pipeline for serving loops (indextts_amd/serving.py) -- several decode chains in flight on their own streams and
+host threads, one acoustic stage behind them -- returns, for every batch, exactly what the sequential `synthesize_batch` returns."""
+import pytest
+import torch
+
+from indextts_amd import synth, weights
+from indextts_amd.config import PipelineConfig
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_batch_pipeline_equals_sequential(device, lanes):
+    from indextts_amd.infer_v2 import IndexTTS2, PromptConditioning
+    from indextts_amd.serving import BatchPipeline
+    cfg = PipelineConfig.tiny()
+    wg = weights.synth_gpt_weights(cfg.gpt, tag="t/serve/gpt")
+    wg["mel_head.bias"] = wg["mel_head.bias"].copy()
+    wg["mel_head.bias"][cfg.gpt.stop_mel_token] = -1e4
+    ws = weights.synth_s2mel_weights(cfg.s2mel, tag="t/serve/s2mel")
+    wv = weights.synth_bigvgan_weights(cfg.bigvgan, tag="t/serve/voc")
+    tts = IndexTTS2.from_state_dicts(cfg, wg, ws, wv, device=device)
+    cond = PromptConditioning.synthetic(cfg, prompt_frames=40, tag="t/serve/prompt").to(device)
+    nb, M = 7, 20
+    Tg = int(M * cfg.code_to_frame)
+    texts = [torch.from_numpy(synth.integers(f"t/serve/text{k}", (2 + k % 3, 9 + k), 2, cfg.gpt.number_text_tokens)) for k in range(nb)]
+    noises = [torch.from_numpy(synth.uniform(f"t/serve/noise{k}", (t.shape[0], cfg.s2mel.in_channels, 40 + Tg), 1.0)).to(device)
+              for k, t in enumerate(texts)]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = [tts.synthesize_batch(t, cond, max_mel_tokens=M, noise=n) for t, n in zip(texts, noises)]
+        torch.cuda.synchronize()
+        with BatchPipeline(tts, decode_lanes=lanes) as pipe:
+            futs = [pipe.submit(t, cond, max_mel_tokens=M, noise=n) for t, n in zip(texts, noises)]
+            got = [f.result() for f in futs]
+    for k in range(nb):
+        assert len(got[k]) == len(want[k])
+        for a, b in zip(got[k], want[k]):
+            assert torch.equal(a, b), k
+
+
+def test_batch_pipeline_propagates_errors(device):
+    from indextts_amd.infer_v2 import IndexTTS2, PromptConditioning
+    from indextts_amd.serving import BatchPipeline
+    cfg = PipelineConfig.tiny()
+    tts = IndexTTS2.from_state_dicts(cfg, weights.synth_gpt_weights(cfg.gpt, tag="t/serve/gpt"), weights.synth_s2mel_weights(cfg.s2mel, tag="t/serve/s2mel"),
+                                     weights.synth_bigvgan_weights(cfg.bigvgan, tag="t/serve/voc"), device=device)
+    cond = PromptConditioning.synthetic(cfg, prompt_frames=40, tag="t/serve/prompt").to(device)
+    bad = torch.full((1, 5), cfg.gpt.number_text_tokens + 7, dtype=torch.long)       # out-of-range token id: rejected on the host
+    with BatchPipeline(tts, decode_lanes=2) as pipe:
+        with pytest.raises(IndexError):
+            pipe.submit(bad, cond, max_mel_tokens=4).result()
+
+
+def test_fullsize_decode_beside_split_bf16_convolutions_is_bit_identical(device):
+    """Regression test of the concurrency defect found in round 2: with packed-FP32 VALU instructions in the build, the decode
+    GEMV's folded-LayerNorm statistics went wrong whenever a split-bf16 convolution of the vocoder ran on the same CUs (bf16
+    MFMAs of another kernel on the SIMD), flipping greedy tokens at near-ties.  Full-size GPT, logits of 6 steps, bit for bit."""
+    import threading
+    import time
+    from indextts_amd import _lib
+    from indextts_amd.gpt import UnifiedVoice
+    from indextts_amd.vocoder import Conv1d
+    cfg = PipelineConfig()
+    wg = weights.synth_gpt_weights(cfg.gpt, tag="bench/gpt")
+    gpt = UnifiedVoice(wg, cfg.gpt, device=device, weight_format="bf16")
+    B, L, M = 16, 64, 6
+    text = torch.from_numpy(synth.integers("t/serve/fulltext", (B, L), 2, cfg.gpt.number_text_tokens))
+    lat = torch.from_numpy(synth.uniform("t/serve/lat", (B, 32, cfg.gpt.model_dim), 0.5)).to(device)
+    emo = torch.from_numpy(synth.uniform("t/serve/emo", (B, cfg.gpt.model_dim), 0.5)).to(device)
+    s = torch.cuda.Stream(device=device)
+
+    def decode():
+        with torch.cuda.stream(s):
+            _, _, logits = gpt.inference_speech(lat, text, emo_vec=emo, max_generate_length=M, repetition_penalty=10.0, do_sample=False,
+                                                num_beams=1, return_logits=True)
+            s.synchronize()
+        return logits
+
+    ref = decode()
+    assert torch.equal(ref, decode())
+    assert _lib.get_gemm_mode() == _lib.GEMM_BF16X3
+    C, T = 768, 3520
+    conv = Conv1d(torch.randn(C, C, 3) * 0.05, torch.zeros(C))
+    x = torch.randn(B, C, T, device=device)
+    out = torch.empty(B, C, T, device=device)
+    stop = threading.Event()
+
+    def load():
+        torch.cuda.set_device(device)
+        sv = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(sv):
+            while not stop.is_set():
+                for _ in range(8):
+                    conv(x, out=out)
+                sv.synchronize()
+
+    th = threading.Thread(target=load)
+    th.start()
+    try:
+        time.sleep(0.2)
+        for _ in range(6):
+            assert torch.equal(decode(), ref)
+    finally:
+        stop.set()
+        th.join()
