@@ -246,6 +246,26 @@ int idxtts_cond_forward(idxtts_ctx* ctx, const float* feats, const int* lengths,
 /* out = base + alpha * (emo - base) over n floats (merge_emovec, model_v2.py:904-910). */
 int idxtts_emovec_merge(float* out, const float* base, const float* emo, float alpha, size_t n, void* stream);
 
+/* ---- semantic features of a prompt (reference: IndexTTS2.get_emb, infer_v2.py:381-408; build_semantic_model,
+ * utils/maskgct_utils.py:87-93) -------------------------------------------------------------------------
+ * The first `num_layers` conformer layers of w2v-bert-2.0 (third-party: transformers' Wav2Vec2BertModel, pinned 4.52.1 by the
+ * reference; `hidden_states[17]` of `output_hidden_states=True` is the INPUT of layer 17, i.e. 17 layers run), then
+ * (x - semantic_mean) / semantic_std.  State-dict keys: Wav2Vec2BertModel's own ("feature_projection.*",
+ * "encoder.layers.{i}.*" for i < num_layers; later layers and "masked_spec_embed" are not consumed), plus the optional
+ * vectors "semantic_mean" / "semantic_std" [hidden_size] (wav2vec2bert_stats.pt: mean, sqrt(var)). */
+typedef struct idxtts_w2vbert_config {
+  int input_dim, hidden_size, num_heads, intermediate_size;   /* 160, 1024, 16, 4096 */
+  int num_layers;                                             /* 17 */
+  int left_max, right_max, conv_kernel;                       /* 64, 8, 31 (relative_key distance embedding; causal depthwise conv) */
+  float layer_norm_eps;                                       /* 1e-5 */
+} idxtts_w2vbert_config;
+int idxtts_w2vbert_create(const idxtts_w2vbert_config* cfg, idxtts_ctx** out);
+size_t idxtts_w2vbert_workspace_bytes(const idxtts_ctx* ctx, int B, int T);
+/* feats: device [B][T][input_dim] (SeamlessM4TFeatureExtractor's input_features); lengths: HOST int32 [B] valid frames
+ * (attention_mask.sum(1)) or NULL = all T; out: device [B][T][hidden_size] (rows t >= lengths[b] are unspecified). */
+int idxtts_w2vbert_forward(idxtts_ctx* ctx, const float* feats, const int* lengths, int B, int T, float* out, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* ---- s2mel stage (reference: infer_v2.py:835-856; MyModel commons.py:390-420) -------------------------
  * State-dict keys: "cfm.estimator.*", "length_regulator.*", "gpt_layer.{0,1,2}.*" (s2mel.pth['net'][...], weight-norm
  * layers folded to plain ".weight"), "semantic_codec.quantizer.quantizers.0.{codebook.weight,out_project.weight,out_project.bias}",

@@ -5,6 +5,7 @@
 #include "../../include/idxtts.h"
 #include "bigvgan.h"
 #include "cond.h"
+#include "semantic.h"
 #include "conv1d.h"
 #include "ctx.h"
 #include "gpt.h"
@@ -413,6 +414,33 @@ int idxtts_cond_forward(idxtts_ctx* ctx, const float* feats, const int* lengths,
   IDX_CHECK(ctx->finalized, "context not finalized");
   auto* m = dynamic_cast<CondModel*>(ctx->model.get());
   IDX_CHECK(m, "not a conditioning-encoder context");
+  return m->forward(feats, lengths, B, T, out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+  API_END
+}
+
+int idxtts_w2vbert_create(const idxtts_w2vbert_config* cfg, idxtts_ctx** out) {
+  API_BEGIN
+  IDX_CHECK(cfg && out, "null pointer");
+  std::unique_ptr<idxtts_ctx> ctx(new idxtts_ctx());
+  ctx->model.reset(new W2VBertModel(*cfg));
+  *out = ctx.release();
+  return 0;
+  API_END
+}
+
+size_t idxtts_w2vbert_workspace_bytes(const idxtts_ctx* ctx, int B, int T) {
+  if (!ctx || !ctx->finalized || B <= 0 || T <= 0) return 0;
+  auto* m = dynamic_cast<const W2VBertModel*>(ctx->model.get());
+  return m ? m->workspace_bytes(B, T) : 0;
+}
+
+int idxtts_w2vbert_forward(idxtts_ctx* ctx, const float* feats, const int* lengths, int B, int T, float* out, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  API_BEGIN
+  IDX_CHECK(ctx, "null ctx");
+  IDX_CHECK(ctx->finalized, "context not finalized");
+  auto* m = dynamic_cast<W2VBertModel*>(ctx->model.get());
+  IDX_CHECK(m, "not a w2v-bert context");
   return m->forward(feats, lengths, B, T, out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
   API_END
 }

@@ -22,6 +22,10 @@ struct SeqAttnArgs {
   const float* bias_u = nullptr; const float* bias_v = nullptr;   // [H][dk]
   float* o = nullptr; int ldo = 0; long o_bs = 0;
   const int* kend = nullptr;                                // [B] device, or null
+  // "relative_key" distance embedding (HF Wav2Vec2BertSelfAttention, modeling_wav2vec2_bert.py relative_key branch):
+  //   scores[j] += scale * q . rel_key[clamp(j - i, -rel_left, rel_right) + rel_left],  rel_key [rel_left+rel_right+1][dk],
+  //   one table shared by every head; null = off
+  const float* rel_key = nullptr; int rel_left = 0, rel_right = 0;
   int B = 0, H = 0, Sq = 0, Sk = 0, dk = 0;
   float scale = 1.0f;
 };
@@ -33,8 +37,10 @@ int mask_rows(float* x, int M, int d, int T, const int* len, hipStream_t st);
 // ConvolutionModule after pointwise_conv1 (conformer_encoder.py:147-158): pw [B*T][2D] ->
 //   g = pw[:, :D] * sigmoid(pw[:, D:])  (GLU);  depthwise conv k (zero pad (k-1)/2 at the ends of each T-row sequence) + bias;
 //   LayerNorm(D, eps 1e-5) * gamma + beta;  SiLU.   y [B*T][D]
+// pad_left < 0: (k-1)/2 (ESPnet "same" padding); pad_left = k-1: the causal form of Wav2Vec2BertConvolutionModule (all padding
+// on the left).  bdw may be null (depthwise conv without bias).
 int glu_dwconv_ln_silu(float* y, const float* pw, const float* wdw /* [D][k] */, const float* bdw, const float* gamma, const float* beta,
-                       int B, int T, int D, int k, hipStream_t st);
+                       int B, int T, int D, int k, hipStream_t st, int pad_left = -1);
 
 // ctx[b][i] = lat[b][i] (i < n), ctx[b][n + t] = x[b][t]   (perceiver.py:305-306 cross_attn_include_queries)
 int concat_latents_ctx(float* ctx, const float* lat, const float* x, int B, int n, int T, int d, hipStream_t st);

@@ -84,15 +84,24 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(const SeqAttnArgs p) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.z, h = blockIdx.y, qi = blockIdx.x * 4 + wave;
   const int dk = p.dk, Sk = p.Sk;
-  float* qu = sm + wave * (2 * dk + ((Sk + 3) & ~3));      // 16-byte aligned per-wave regions
+  const int nrel = p.rel_key ? p.rel_left + p.rel_right + 1 : 0, nrel4 = (nrel + 3) & ~3;
+  float* qu = sm + wave * (2 * dk + nrel4 + ((Sk + 3) & ~3));      // 16-byte aligned per-wave regions
   float* qv = qu + dk;
-  float* sc = qv + dk;
+  float* rel = qv + dk;             // [nrel] q . rel_key[d]
+  float* sc = rel + nrel4;
   if (qi >= p.Sq) return;           // whole wave; no workgroup barrier below
   const float* q = p.q + (size_t)b * p.q_bs + (size_t)qi * p.ldq + h * dk;
   for (int e = lane; e < dk; e += 64) {
     const float v = q[e];
     qu[e] = v + (p.bias_u ? p.bias_u[h * dk + e] : 0.0f);
     qv[e] = v + (p.bias_v ? p.bias_v[h * dk + e] : 0.0f);
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int r = lane; r < nrel; r += 64) {
+    const float* er = p.rel_key + (size_t)r * dk;
+    float s = 0.0f;
+    for (int e = 0; e < dk; ++e) s = fmaf(qu[e], er[e], s);
+    rel[r] = s;
   }
   __builtin_amdgcn_wave_barrier();
   const int kend = p.kend ? min(p.kend[b], Sk) : Sk;
@@ -115,6 +124,7 @@ __global__ __launch_bounds__(256) void seq_attn_kernel(const SeqAttnArgs p) {
       }
       s += s2;
     }
+    if (nrel) s += rel[min(max(j - qi, -p.rel_left), p.rel_right) + p.rel_left];
     s *= p.scale;
     sc[j] = s;
     mx = fmaxf(mx, s);
@@ -144,7 +154,9 @@ int seq_attn_forward(const SeqAttnArgs& a, hipStream_t st) {
   IDX_CHECK(a.dk > 0 && a.dk <= 128 && (a.dk & 3) == 0, "head_dim must be a multiple of 4, at most 128");
   IDX_CHECK((a.ldk & 3) == 0 && (a.k_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(a.k) & 15) == 0, "k rows must be 16-byte aligned");
   if (a.pos) IDX_CHECK((a.ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(a.pos) & 15) == 0 && a.bias_u && a.bias_v, "position term");
-  const size_t lds = (size_t)4 * (2 * a.dk + ((a.Sk + 3) & ~3)) * sizeof(float);
+  if (a.rel_key) IDX_CHECK(a.rel_left >= 0 && a.rel_right >= 0 && !a.bias_u && !a.pos && a.Sq == a.Sk, "relative_key: self-attention without the rel-pos term");
+  const int nrel4 = a.rel_key ? (a.rel_left + a.rel_right + 1 + 3) & ~3 : 0;
+  const size_t lds = (size_t)4 * (2 * a.dk + nrel4 + ((a.Sk + 3) & ~3)) * sizeof(float);
   IDX_CHECK(lds <= 64 * 1024, "key sequence too long for the short-sequence attention kernel");
   ProfScope prof(PROF_ELTWISE, st, (a.pos ? 6.0 : 4.0) * a.B * a.H * (double)a.Sq * a.Sk * a.dk,
                  4.0 * a.B * a.H * a.dk * (2.0 * a.Sq + 2.0 * a.Sk));
@@ -172,10 +184,9 @@ int mask_rows(float* x, int M, int d, int T, const int* len, hipStream_t st) {
 constexpr int DW_MAX_PER_THREAD = 4;    // D <= 1024
 
 __global__ __launch_bounds__(256) void glu_dwconv_ln_silu_kernel(float* y, const float* pw, const float* wdw, const float* bdw,
-                                                                 const float* gamma, const float* beta, int T, int D, int k) {
+                                                                 const float* gamma, const float* beta, int T, int D, int k, int pad) {
   __shared__ float red[4];
   const int m = blockIdx.x, b = m / T, t = m - b * T, tid = threadIdx.x;
-  const int pad = (k - 1) / 2;
   float v[DW_MAX_PER_THREAD];
   float s = 0.0f;
 #pragma unroll
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(256) void glu_dwconv_ln_silu_kernel(float* y, const
     const int c = tid + 256 * i;
     float acc = 0.0f;
     if (c < D) {
-      acc = bdw[c];
+      acc = bdw ? bdw[c] : 0.0f;
       for (int kk = 0; kk < k; ++kk) {
         const int tt = t + kk - pad;
         if (tt < 0 || tt >= T) continue;
@@ -211,11 +222,12 @@ __global__ __launch_bounds__(256) void glu_dwconv_ln_silu_kernel(float* y, const
 }
 
 int glu_dwconv_ln_silu(float* y, const float* pw, const float* wdw, const float* bdw, const float* gamma, const float* beta, int B, int T,
-                       int D, int k, hipStream_t st) {
-  IDX_CHECK(y && pw && wdw && bdw && gamma && beta, "null pointer");
-  IDX_CHECK(B > 0 && T > 0 && D > 0 && D <= 256 * DW_MAX_PER_THREAD && (k & 1) == 1, "shape");
+                       int D, int k, hipStream_t st, int pad_left) {
+  IDX_CHECK(y && pw && wdw && gamma && beta, "null pointer");
+  IDX_CHECK(B > 0 && T > 0 && D > 0 && D <= 256 * DW_MAX_PER_THREAD && (k & 1) == 1 && pad_left < k, "shape");
   ProfScope prof(PROF_ELTWISE, st, 0.0, 4.0 * B * T * 3.0 * D);
-  hipLaunchKernelGGL(glu_dwconv_ln_silu_kernel, dim3(B * T), dim3(256), 0, st, y, pw, wdw, bdw, gamma, beta, T, D, k);
+  hipLaunchKernelGGL(glu_dwconv_ln_silu_kernel, dim3(B * T), dim3(256), 0, st, y, pw, wdw, bdw, gamma, beta, T, D, k,
+                     pad_left < 0 ? (k - 1) / 2 : pad_left);
   IDX_LAUNCH_CHECK();
   return 0;
 }

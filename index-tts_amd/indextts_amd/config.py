@@ -170,3 +170,23 @@ class PipelineConfig:
         return PipelineConfig(gpt=g, s2mel=s,
                               bigvgan=BigVGANConfig(num_mels=s.in_channels, upsample_initial_channel=64),
                               diffusion_steps=3)
+
+
+@dataclass(frozen=True)
+class W2VBertConfig:
+    """facebook/w2v-bert-2.0 as the reference uses it (utils/maskgct_utils.py:87-93; infer_v2.py:381-408 reads
+    hidden_states[17]): HF Wav2Vec2BertConfig's defaults, `num_layers` = the layers that have to run."""
+    input_dim: int = 160
+    hidden_size: int = 1024
+    num_heads: int = 16
+    intermediate_size: int = 4096
+    num_layers: int = 17
+    left_max: int = 64
+    right_max: int = 8
+    conv_kernel: int = 31
+    layer_norm_eps: float = 1e-5
+
+    @staticmethod
+    def tiny() -> "W2VBertConfig":
+        return W2VBertConfig(input_dim=24, hidden_size=64, num_heads=4, intermediate_size=128, num_layers=3, left_max=6, right_max=3,
+                             conv_kernel=7)

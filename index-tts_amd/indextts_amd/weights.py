@@ -16,7 +16,7 @@ from typing import Dict
 import numpy as np
 
 from . import synth
-from .config import BigVGANConfig, GPTConfig, S2MelConfig
+from .config import BigVGANConfig, GPTConfig, S2MelConfig, W2VBertConfig
 
 Weights = Dict[str, np.ndarray]
 
@@ -257,4 +257,49 @@ def synth_s2mel_weights(cfg: S2MelConfig, tag: str = "s2mel") -> Weights:
     w["semantic_codec.quantizer.quantizers.0.codebook.weight"] = synth.uniform(
         f"{tag}/semantic_codec.codebook", (cfg.codebook_size, cfg.codebook_dim), 1.0)
     conv("semantic_codec.quantizer.quantizers.0.out_project", cfg.codec_hidden, cfg.codebook_dim, 1)
+    return w
+
+
+# --------------------------------------------------------------------------------------
+# w2v-bert-2.0 (HF Wav2Vec2BertModel.state_dict(), the layers the reference runs: infer_v2.py:381-408)
+# --------------------------------------------------------------------------------------
+def synth_w2vbert_weights(cfg: W2VBertConfig, tag: str = "w2vbert", stats: bool = True) -> Weights:
+    """Keys / shapes of `Wav2Vec2BertModel.state_dict()` for `feature_projection.*` and `encoder.layers.{i}.*`, i < cfg.num_layers,
+    plus `semantic_mean` / `semantic_std` (wav2vec2bert_stats.pt: mean, sqrt(var); maskgct_utils.py:90-92)."""
+    w: Weights = {}
+    D, F, hd = cfg.hidden_size, cfg.intermediate_size, cfg.hidden_size // cfg.num_heads
+
+    def u(name, shape, scale, offset=0.0):
+        w[name] = synth.uniform(f"{tag}/{name}", shape, scale, offset)
+
+    def lin(name, n_out, n_in, gain=1.0, bias=True):
+        w[f"{name}.weight"] = synth.fan_in_uniform(f"{tag}/{name}.weight", (n_out, n_in), n_in, gain)
+        if bias:
+            u(f"{name}.bias", (n_out,), 0.05)
+
+    def ln(name, n):
+        u(f"{name}.weight", (n,), 0.2, 1.0)
+        u(f"{name}.bias", (n,), 0.1)
+
+    ln("feature_projection.layer_norm", cfg.input_dim)
+    lin("feature_projection.projection", D, cfg.input_dim, 1.4)
+    for i in range(cfg.num_layers):
+        e = f"encoder.layers.{i}"
+        for nm in ("ffn1_layer_norm", "self_attn_layer_norm", "conv_module.layer_norm", "conv_module.depthwise_layer_norm", "ffn2_layer_norm",
+                   "final_layer_norm"):
+            ln(f"{e}.{nm}", D)
+        for f in ("ffn1", "ffn2"):
+            lin(f"{e}.{f}.intermediate_dense", F, D, 1.2)
+            lin(f"{e}.{f}.output_dense", D, F, 0.9)
+        for nm in ("linear_q", "linear_k", "linear_v"):
+            lin(f"{e}.self_attn.{nm}", D, D, 1.3)
+        lin(f"{e}.self_attn.linear_out", D, D, 0.8)
+        u(f"{e}.self_attn.distance_embedding.weight", (cfg.left_max + cfg.right_max + 1, hd), 0.4)
+        w[f"{e}.conv_module.pointwise_conv1.weight"] = synth.fan_in_uniform(f"{tag}/{e}.conv_module.pointwise_conv1.weight", (2 * D, D, 1), D, 1.3)
+        w[f"{e}.conv_module.depthwise_conv.weight"] = synth.fan_in_uniform(f"{tag}/{e}.conv_module.depthwise_conv.weight", (D, 1, cfg.conv_kernel),
+                                                                          cfg.conv_kernel, 1.6)
+        w[f"{e}.conv_module.pointwise_conv2.weight"] = synth.fan_in_uniform(f"{tag}/{e}.conv_module.pointwise_conv2.weight", (D, D, 1), D, 0.9)
+    if stats:
+        u("semantic_mean", (D,), 0.3)
+        u("semantic_std", (D,), 0.4, 1.0)
     return w

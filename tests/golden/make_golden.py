@@ -681,6 +681,46 @@ def make_segments():
     print("wrote segments.json", len(cases), "cases")
 
 
+def make_w2vbert():
+    """Semantic-feature fixtures from the container's own `transformers.Wav2Vec2BertModel` (the class the reference instantiates,
+    utils/maskgct_utils.py:88) carrying the synthetic weights: `hidden_states[n]` exactly as `IndexTTS2.get_emb` reads it
+    (infer_v2.py:399-406), a ragged batch with an attention mask and a single unpadded row, at the tiny sizes."""
+    from transformers import Wav2Vec2BertConfig, Wav2Vec2BertModel
+    from indextts_amd import synth, weights
+    from indextts_amd.config import W2VBertConfig
+    cfg = W2VBertConfig.tiny()
+    w = weights.synth_w2vbert_weights(cfg, tag="golden/w2vbert")
+    hc = Wav2Vec2BertConfig(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_layers + 1, num_attention_heads=cfg.num_heads,
+                            intermediate_size=cfg.intermediate_size, feature_projection_input_dim=cfg.input_dim,
+                            left_max_position_embeddings=cfg.left_max, right_max_position_embeddings=cfg.right_max,
+                            conv_depthwise_kernel_size=cfg.conv_kernel, layer_norm_eps=cfg.layer_norm_eps, apply_spec_augment=False,
+                            hidden_dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, feat_proj_dropout=0.0, layerdrop=0.0,
+                            conformer_conv_dropout=0.0)
+    model = Wav2Vec2BertModel(hc).eval()
+    sd = {k: torch.from_numpy(v) for k, v in w.items() if k not in ("semantic_mean", "semantic_std")}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(m.startswith(f"encoder.layers.{cfg.num_layers}.") or m == "masked_spec_embed" for m in missing), missing
+    B, T = 3, 37
+    feats = torch.from_numpy(synth.uniform("golden/w2vbert/feats", (B, T, cfg.input_dim), 1.5))
+    lens = torch.tensor([37, 22, 30])
+    mask = (torch.arange(T)[None, :] < lens[:, None]).long()
+    mean, std = torch.from_numpy(w["semantic_mean"]), torch.from_numpy(w["semantic_std"])
+    with torch.no_grad():
+        hs = model(input_features=feats, attention_mask=mask, output_hidden_states=True).hidden_states
+        assert len(hs) == cfg.num_layers + 2
+        ragged = (hs[cfg.num_layers] - mean) / std
+        solo = (model(input_features=feats[1:2, :22], output_hidden_states=True).hidden_states[cfg.num_layers] - mean) / std
+        proj = hs[0]
+        layer0 = hs[1]
+    out = {"feats": feats.numpy(), "lens": lens.numpy().astype(np.int32), "mask": mask.numpy().astype(np.int32), "emb_ragged": ragged.numpy(),
+           "emb_row1_alone": solo.numpy(), "hidden0": proj.numpy(), "hidden1": layer0.numpy()}
+    # the ragged batch's valid frames must equal the unpadded run (what "padding never reaches a valid frame" means)
+    assert np.abs(out["emb_ragged"][1, :22] - out["emb_row1_alone"][0]).max() < 1e-4
+    np.savez_compressed(os.path.join(HERE, "w2vbert.npz"), **out)
+    print("w2vbert.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     torch.manual_seed(0)
@@ -688,6 +728,8 @@ if __name__ == "__main__":
         make_gpt()
     if which in ("gpt_ref", "all"):
         make_gpt_ref()
+    if which in ("w2vbert", "all"):
+        make_w2vbert()
     if which in ("vocoder", "s2mel", "all"):
         Munch = _install_placeholders()
         if which in ("vocoder", "all"):
