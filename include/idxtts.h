@@ -266,6 +266,21 @@ size_t idxtts_w2vbert_workspace_bytes(const idxtts_ctx* ctx, int B, int T);
 int idxtts_w2vbert_forward(idxtts_ctx* ctx, const float* feats, const int* lengths, int B, int T, float* out, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* ---- semantic codec, `quantize` (reference: `_, S_ref = self.semantic_codec.quantize(spk_cond_emb)`, infer_v2.py:637; RepCodec,
+ * utils/maskgct/models/codec/kmeans/repcodec_model.py:179-199; build_semantic_codec, utils/maskgct_utils.py:96-99) ------
+ * State-dict keys: RepCodec's own, "encoder.*" (VocosBackbone + Linear) and "quantizer.quantizers.0.{in_project,out_project,
+ * codebook}.*" with the weight-norm pairs folded to plain ".weight"; "decoder.*" is not consumed. */
+typedef struct idxtts_repcodec_config {
+  int hidden_size, codebook_size, codebook_dim;                   /* 1024, 8192, 8 */
+  int vocos_dim, vocos_intermediate_dim, vocos_num_layers;        /* 384, 2048, 12 */
+} idxtts_repcodec_config;
+int idxtts_repcodec_create(const idxtts_repcodec_config* cfg, idxtts_ctx** out);
+size_t idxtts_repcodec_workspace_bytes(const idxtts_ctx* ctx, int B, int T);
+/* x: device [B][T][hidden_size] (the normalised w2v-bert features); indices: device int64 [B][T]; quantized: device
+ * [B][T][hidden_size] (= quantize(x)[1], already transposed back to token-major: the S_ref the length regulator takes). */
+int idxtts_repcodec_quantize(idxtts_ctx* ctx, const float* x, int B, int T, long long* indices, float* quantized, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 /* ---- s2mel stage (reference: infer_v2.py:835-856; MyModel commons.py:390-420) -------------------------
  * State-dict keys: "cfm.estimator.*", "length_regulator.*", "gpt_layer.{0,1,2}.*" (s2mel.pth['net'][...], weight-norm
  * layers folded to plain ".weight"), "semantic_codec.quantizer.quantizers.0.{codebook.weight,out_project.weight,out_project.bias}",

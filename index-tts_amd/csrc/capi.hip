@@ -6,6 +6,7 @@
 #include "bigvgan.h"
 #include "cond.h"
 #include "semantic.h"
+#include "codec.h"
 #include "conv1d.h"
 #include "ctx.h"
 #include "gpt.h"
@@ -442,6 +443,33 @@ int idxtts_w2vbert_forward(idxtts_ctx* ctx, const float* feats, const int* lengt
   auto* m = dynamic_cast<W2VBertModel*>(ctx->model.get());
   IDX_CHECK(m, "not a w2v-bert context");
   return m->forward(feats, lengths, B, T, out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+  API_END
+}
+
+int idxtts_repcodec_create(const idxtts_repcodec_config* cfg, idxtts_ctx** out) {
+  API_BEGIN
+  IDX_CHECK(cfg && out, "null pointer");
+  std::unique_ptr<idxtts_ctx> ctx(new idxtts_ctx());
+  ctx->model.reset(new RepCodecModel(*cfg));
+  *out = ctx.release();
+  return 0;
+  API_END
+}
+
+size_t idxtts_repcodec_workspace_bytes(const idxtts_ctx* ctx, int B, int T) {
+  if (!ctx || !ctx->finalized || B <= 0 || T <= 0) return 0;
+  auto* m = dynamic_cast<const RepCodecModel*>(ctx->model.get());
+  return m ? m->workspace_bytes(B, T) : 0;
+}
+
+int idxtts_repcodec_quantize(idxtts_ctx* ctx, const float* x, int B, int T, long long* indices, float* quantized, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  API_BEGIN
+  IDX_CHECK(ctx, "null ctx");
+  IDX_CHECK(ctx->finalized, "context not finalized");
+  auto* m = dynamic_cast<RepCodecModel*>(ctx->model.get());
+  IDX_CHECK(m, "not a semantic-codec context");
+  return m->quantize(x, B, T, indices, quantized, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
   API_END
 }
 

@@ -42,6 +42,11 @@ int mask_rows(float* x, int M, int d, int T, const int* len, hipStream_t st);
 int glu_dwconv_ln_silu(float* y, const float* pw, const float* wdw /* [D][k] */, const float* bdw, const float* gamma, const float* beta,
                        int B, int T, int D, int k, hipStream_t st, int pad_left = -1);
 
+// ConvNeXt block head (kmeans/vocos.py:507-517): depthwise Conv1d k ("same" zero padding) + bias over token-major rows x [B*T][D],
+// then LayerNorm(D, eps) * gamma + beta.
+int dwconv_ln(float* y, const float* x, const float* wdw /* [D][k] */, const float* bdw, const float* gamma, const float* beta, int B, int T,
+              int D, int k, float eps, hipStream_t st);
+
 // ctx[b][i] = lat[b][i] (i < n), ctx[b][n + t] = x[b][t]   (perceiver.py:305-306 cross_attn_include_queries)
 int concat_latents_ctx(float* ctx, const float* lat, const float* x, int B, int n, int T, int d, hipStream_t st);
 

@@ -183,10 +183,13 @@ int mask_rows(float* x, int M, int d, int T, const int* len, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------
 constexpr int DW_MAX_PER_THREAD = 4;    // D <= 1024
 
-__global__ __launch_bounds__(256) void glu_dwconv_ln_silu_kernel(float* y, const float* pw, const float* wdw, const float* bdw,
-                                                                 const float* gamma, const float* beta, int T, int D, int k, int pad) {
+// GLU: the input rows are [2D] = (a | gate) and the conv runs over a * sigmoid(gate); SILU: swish after the LayerNorm.
+template <bool GLU, bool SILU>
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(float* y, const float* pw, const float* wdw, const float* bdw, const float* gamma,
+                                                        const float* beta, int T, int D, int k, int pad, float eps) {
   __shared__ float red[4];
   const int m = blockIdx.x, b = m / T, t = m - b * T, tid = threadIdx.x;
+  const int ld = GLU ? 2 * D : D;
   float v[DW_MAX_PER_THREAD];
   float s = 0.0f;
 #pragma unroll
@@ -198,9 +201,10 @@ __global__ __launch_bounds__(256) void glu_dwconv_ln_silu_kernel(float* y, const
       for (int kk = 0; kk < k; ++kk) {
         const int tt = t + kk - pad;
         if (tt < 0 || tt >= T) continue;
-        const float* row = pw + ((size_t)b * T + tt) * 2 * D;
-        const float a = row[c], g = row[D + c];
-        acc = fmaf(wdw[c * k + kk], a * (1.0f / (1.0f + expf(-g))), acc);
+        const float* row = pw + ((size_t)b * T + tt) * ld;
+        float a = row[c];
+        if (GLU) a *= 1.0f / (1.0f + expf(-row[D + c]));
+        acc = fmaf(wdw[c * k + kk], a, acc);
       }
       s += acc;
     }
@@ -210,13 +214,13 @@ __global__ __launch_bounds__(256) void glu_dwconv_ln_silu_kernel(float* y, const
   float ss = 0.0f;
 #pragma unroll
   for (int i = 0; i < DW_MAX_PER_THREAD; ++i) { const int c = tid + 256 * i; if (c < D) { const float dlt = v[i] - mean; ss += dlt * dlt; } }
-  const float rstd = rsqrtf(bsum256(ss, red) / D + 1e-5f);
+  const float rstd = rsqrtf(bsum256(ss, red) / D + eps);
 #pragma unroll
   for (int i = 0; i < DW_MAX_PER_THREAD; ++i) {
     const int c = tid + 256 * i;
     if (c < D) {
       const float n = (v[i] - mean) * rstd * gamma[c] + beta[c];
-      y[(size_t)m * D + c] = n / (1.0f + expf(-n));
+      y[(size_t)m * D + c] = SILU ? n / (1.0f + expf(-n)) : n;
     }
   }
 }
@@ -226,8 +230,18 @@ int glu_dwconv_ln_silu(float* y, const float* pw, const float* wdw, const float*
   IDX_CHECK(y && pw && wdw && gamma && beta, "null pointer");
   IDX_CHECK(B > 0 && T > 0 && D > 0 && D <= 256 * DW_MAX_PER_THREAD && (k & 1) == 1 && pad_left < k, "shape");
   ProfScope prof(PROF_ELTWISE, st, 0.0, 4.0 * B * T * 3.0 * D);
-  hipLaunchKernelGGL(glu_dwconv_ln_silu_kernel, dim3(B * T), dim3(256), 0, st, y, pw, wdw, bdw, gamma, beta, T, D, k,
-                     pad_left < 0 ? (k - 1) / 2 : pad_left);
+  hipLaunchKernelGGL((dwconv_ln_kernel<true, true>), dim3(B * T), dim3(256), 0, st, y, pw, wdw, bdw, gamma, beta, T, D, k,
+                     pad_left < 0 ? (k - 1) / 2 : pad_left, 1e-5f);
+  IDX_LAUNCH_CHECK();
+  return 0;
+}
+
+int dwconv_ln(float* y, const float* x, const float* wdw, const float* bdw, const float* gamma, const float* beta, int B, int T, int D, int k,
+              float eps, hipStream_t st) {
+  IDX_CHECK(y && x && wdw && gamma && beta, "null pointer");
+  IDX_CHECK(B > 0 && T > 0 && D > 0 && D <= 256 * DW_MAX_PER_THREAD && (k & 1) == 1, "shape");
+  ProfScope prof(PROF_ELTWISE, st, 0.0, 4.0 * B * T * 2.0 * D);
+  hipLaunchKernelGGL((dwconv_ln_kernel<false, false>), dim3(B * T), dim3(256), 0, st, y, x, wdw, bdw, gamma, beta, T, D, k, (k - 1) / 2, eps);
   IDX_LAUNCH_CHECK();
   return 0;
 }

@@ -27,6 +27,7 @@ SYMBOLS = [
     "idxtts_s2mel_cfm_workspace_bytes", "idxtts_s2mel_cfm", "idxtts_set_gemm_mode", "idxtts_get_gemm_mode",
     "idxtts_s2mel_estimator", "idxtts_s2mel_regulate", "idxtts_cond_create", "idxtts_cond_workspace_bytes", "idxtts_cond_forward", "idxtts_emovec_merge",
     "idxtts_w2vbert_create", "idxtts_w2vbert_workspace_bytes", "idxtts_w2vbert_forward",
+    "idxtts_repcodec_create", "idxtts_repcodec_workspace_bytes", "idxtts_repcodec_quantize",
 ]
 
 
@@ -58,6 +59,10 @@ class CondConfigC(ctypes.Structure):         # idxtts_cond_config (include/idxtt
 class W2VBertConfigC(ctypes.Structure):      # idxtts_w2vbert_config (include/idxtts.h)
     _fields_ = [(n, c_int) for n in ("input_dim", "hidden_size", "num_heads", "intermediate_size", "num_layers", "left_max", "right_max",
                                      "conv_kernel")] + [("layer_norm_eps", c_float)]
+
+
+class RepCodecConfigC(ctypes.Structure):     # idxtts_repcodec_config (include/idxtts.h)
+    _fields_ = [(n, c_int) for n in ("hidden_size", "codebook_size", "codebook_dim", "vocos_dim", "vocos_intermediate_dim", "vocos_num_layers")]
 
 
 class BeamC(ctypes.Structure):               # idxtts_beam (include/idxtts.h)
@@ -148,6 +153,10 @@ def load() -> ctypes.CDLL:
     lib.idxtts_cond_workspace_bytes.restype = c_size_t
     lib.idxtts_cond_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.idxtts_emovec_merge.argtypes = [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]
+    lib.idxtts_repcodec_create.argtypes = [POINTER(RepCodecConfigC), POINTER(c_void_p)]
+    lib.idxtts_repcodec_workspace_bytes.argtypes = [c_void_p, c_int, c_int]
+    lib.idxtts_repcodec_workspace_bytes.restype = c_size_t
+    lib.idxtts_repcodec_quantize.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.idxtts_w2vbert_create.argtypes = [POINTER(W2VBertConfigC), POINTER(c_void_p)]
     lib.idxtts_w2vbert_workspace_bytes.argtypes = [c_void_p, c_int, c_int]
     lib.idxtts_w2vbert_workspace_bytes.restype = c_size_t

@@ -190,3 +190,18 @@ class W2VBertConfig:
     def tiny() -> "W2VBertConfig":
         return W2VBertConfig(input_dim=24, hidden_size=64, num_heads=4, intermediate_size=128, num_layers=3, left_max=6, right_max=3,
                              conv_kernel=7)
+
+
+@dataclass(frozen=True)
+class RepCodecConfig:
+    """The semantic codec (checkpoints/config.yaml:45-51 `semantic_codec`; RepCodec, kmeans/repcodec_model.py:35-146)."""
+    hidden_size: int = 1024
+    codebook_size: int = 8192
+    codebook_dim: int = 8
+    vocos_dim: int = 384
+    vocos_intermediate_dim: int = 2048
+    vocos_num_layers: int = 12
+
+    @staticmethod
+    def tiny() -> "RepCodecConfig":
+        return RepCodecConfig(hidden_size=64, codebook_size=57, codebook_dim=4, vocos_dim=32, vocos_intermediate_dim=48, vocos_num_layers=2)

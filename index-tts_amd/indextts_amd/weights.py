@@ -16,7 +16,7 @@ from typing import Dict
 import numpy as np
 
 from . import synth
-from .config import BigVGANConfig, GPTConfig, S2MelConfig, W2VBertConfig
+from .config import BigVGANConfig, GPTConfig, RepCodecConfig, S2MelConfig, W2VBertConfig
 
 Weights = Dict[str, np.ndarray]
 
@@ -302,4 +302,45 @@ def synth_w2vbert_weights(cfg: W2VBertConfig, tag: str = "w2vbert", stats: bool 
     if stats:
         u("semantic_mean", (D,), 0.3)
         u("semantic_std", (D,), 0.4, 1.0)
+    return w
+
+
+# --------------------------------------------------------------------------------------
+# RepCodec, the semantic codec's encoder + quantizer (kmeans/repcodec_model.py:105-146; weight-norm pairs folded)
+# --------------------------------------------------------------------------------------
+def synth_repcodec_weights(cfg: RepCodecConfig, tag: str = "repcodec") -> Weights:
+    """Keys / shapes of `RepCodec.state_dict()` on the `quantize` path: `encoder.0.*` (VocosBackbone), `encoder.1.*` (Linear),
+    `quantizer.quantizers.0.{in_project,out_project}.{weight,bias}` (1x1 convs, weight norm folded) and `.codebook.weight`."""
+    w: Weights = {}
+    Hs, D, F, cd = cfg.hidden_size, cfg.vocos_dim, cfg.vocos_intermediate_dim, cfg.codebook_dim
+
+    def u(name, shape, scale, offset=0.0):
+        w[name] = synth.uniform(f"{tag}/{name}", shape, scale, offset)
+
+    def ln(name, n):
+        u(f"{name}.weight", (n,), 0.2, 1.0)
+        u(f"{name}.bias", (n,), 0.1)
+
+    w["encoder.0.embed.weight"] = synth.fan_in_uniform(f"{tag}/encoder.0.embed.weight", (D, Hs, 7), Hs * 7, 1.5)
+    u("encoder.0.embed.bias", (D,), 0.1)
+    ln("encoder.0.norm", D)
+    for i in range(cfg.vocos_num_layers):
+        e = f"encoder.0.convnext.{i}"
+        w[f"{e}.dwconv.weight"] = synth.fan_in_uniform(f"{tag}/{e}.dwconv.weight", (D, 1, 7), 7, 1.5)
+        u(f"{e}.dwconv.bias", (D,), 0.1)
+        ln(f"{e}.norm", D)
+        w[f"{e}.pwconv1.weight"] = synth.fan_in_uniform(f"{tag}/{e}.pwconv1.weight", (F, D), D, 1.3)
+        u(f"{e}.pwconv1.bias", (F,), 0.1)
+        w[f"{e}.pwconv2.weight"] = synth.fan_in_uniform(f"{tag}/{e}.pwconv2.weight", (D, F), F, 1.2)
+        u(f"{e}.pwconv2.bias", (D,), 0.1)
+        u(f"{e}.gamma", (D,), 0.3, 0.6)
+    ln("encoder.0.final_layer_norm", D)
+    w["encoder.1.weight"] = synth.fan_in_uniform(f"{tag}/encoder.1.weight", (Hs, D), D, 1.4)
+    u("encoder.1.bias", (Hs,), 0.1)
+    q = "quantizer.quantizers.0"
+    w[f"{q}.in_project.weight"] = synth.fan_in_uniform(f"{tag}/{q}.in_project.weight", (cd, Hs, 1), Hs, 1.5)
+    u(f"{q}.in_project.bias", (cd,), 0.1)
+    w[f"{q}.out_project.weight"] = synth.fan_in_uniform(f"{tag}/{q}.out_project.weight", (Hs, cd, 1), cd, 1.0)
+    u(f"{q}.out_project.bias", (Hs,), 0.1)
+    u(f"{q}.codebook.weight", (cfg.codebook_size, cd), 1.0)
     return w

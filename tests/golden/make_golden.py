@@ -721,6 +721,49 @@ def make_w2vbert():
     print("w2vbert.npz", {k: v.shape for k, v in out.items()})
 
 
+def make_repcodec():
+    """Semantic-codec fixtures from the reference's own RepCodec class (kmeans/repcodec_model.py) carrying the synthetic weights:
+    `quantize(x)` as the prompt block calls it (infer_v2.py:637), plus the encoder output and the projected latents so a test can
+    tell a near-tie of the nearest-code search from an error."""
+    _install_placeholders()
+    ff = types.ModuleType("torchaudio.functional.functional")
+    ff._hz_to_mel = ff._mel_to_hz = None
+    sys.modules["torchaudio.functional"] = types.ModuleType("torchaudio.functional")
+    sys.modules["torchaudio.functional.functional"] = ff
+    from indextts.utils.maskgct.models.codec.kmeans.repcodec_model import RepCodec
+    from indextts_amd import synth, weights
+    from indextts_amd.config import RepCodecConfig
+    cfg = RepCodecConfig.tiny()
+    w = weights.synth_repcodec_weights(cfg, tag="golden/repcodec")
+    m = RepCodec(codebook_size=cfg.codebook_size, hidden_size=cfg.hidden_size, codebook_dim=cfg.codebook_dim, vocos_dim=cfg.vocos_dim,
+                 vocos_intermediate_dim=cfg.vocos_intermediate_dim, vocos_num_layers=cfg.vocos_num_layers).eval()
+    sd = m.state_dict()
+    loaded = {}
+    for k, v in w.items():
+        if k.endswith("_project.weight"):          # weight-norm pair: g = ||v|| makes the effective weight v itself
+            t = torch.from_numpy(v)
+            loaded[k[:-len("weight")] + "weight_v"] = t
+            loaded[k[:-len("weight")] + "weight_g"] = t.reshape(t.shape[0], -1).norm(dim=1).reshape(-1, 1, 1)
+        else:
+            loaded[k] = torch.from_numpy(v)
+    assert set(loaded) <= set(sd), sorted(set(loaded) - set(sd))
+    assert all(k.startswith("decoder.") for k in set(sd) - set(loaded)), sorted(k for k in set(sd) - set(loaded) if not k.startswith("decoder."))
+    m.load_state_dict(loaded, strict=False)
+    B, T = 2, 23
+    x = torch.from_numpy(synth.uniform("golden/repcodec/x", (B, T, cfg.hidden_size), 1.0))
+    with torch.no_grad():
+        idx, q = m.quantize(x)
+        enc = m.encoder(x.transpose(1, 2))                                     # [B, T, hidden]
+        ze = m.quantizer.quantizers[0].in_project(enc.transpose(1, 2))         # [B, d, T]
+        x1 = x[:1]
+        idx1, q1 = m.quantize(x1)
+    assert idx.shape == (B, T) and q.shape == (B, T, cfg.hidden_size) and idx1.shape == (1, T)
+    out = {"x": x.numpy(), "indices": idx.numpy(), "quantized": q.numpy(), "encoded": enc.numpy(), "z_e": ze.transpose(1, 2).numpy(),
+           "indices_b1": idx1.numpy(), "quantized_b1": q1.numpy()}
+    np.savez_compressed(os.path.join(HERE, "repcodec.npz"), **out)
+    print("repcodec.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     torch.manual_seed(0)
@@ -739,3 +782,5 @@ if __name__ == "__main__":
     if which in ("segments", "all"):
         _install_placeholders()
         make_segments()
+    if which in ("repcodec", "all"):
+        make_repcodec()
