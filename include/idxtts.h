@@ -281,6 +281,20 @@ size_t idxtts_repcodec_workspace_bytes(const idxtts_ctx* ctx, int B, int T);
 int idxtts_repcodec_quantize(idxtts_ctx* ctx, const float* x, int B, int T, long long* indices, float* quantized, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/* ---- log-mel spectrogram of the prompt (reference: `ref_mel = self.mel_fn(audio_22k)`, infer_v2.py:291-301, 640;
+ * mel_spectrogram, s2mel/modules/audio.py:45-83) -----------------------------------------------------------------------
+ * Tensors of the context: "mel_basis" [num_mels][n_fft/2+1] (the reference's librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax))
+ * and "window" [win_size] (torch.hann_window(win_size)). */
+typedef struct idxtts_melspec_config {
+  int n_fft, hop_size, win_size, num_mels;          /* 1024, 256, 1024, 80 */
+} idxtts_melspec_config;
+int idxtts_melspec_create(const idxtts_melspec_config* cfg, idxtts_ctx** out);
+int idxtts_melspec_frames(const idxtts_ctx* ctx, int n_samples);       /* (n_samples + 2 * ((n_fft - hop) / 2) - n_fft) / hop + 1 */
+size_t idxtts_melspec_workspace_bytes(const idxtts_ctx* ctx, int B, int n_samples);
+/* audio: device [B][n_samples] in [-1, 1]; mel: device [B][num_mels][frames] = log(clamp(mel_basis @ |STFT|, 1e-5)). */
+int idxtts_melspec_forward(idxtts_ctx* ctx, const float* audio, int B, int n_samples, float* mel, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
 /* ---- s2mel stage (reference: infer_v2.py:835-856; MyModel commons.py:390-420) -------------------------
  * State-dict keys: "cfm.estimator.*", "length_regulator.*", "gpt_layer.{0,1,2}.*" (s2mel.pth['net'][...], weight-norm
  * layers folded to plain ".weight"), "semantic_codec.quantizer.quantizers.0.{codebook.weight,out_project.weight,out_project.bias}",

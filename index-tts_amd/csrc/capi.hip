@@ -7,6 +7,7 @@
 #include "cond.h"
 #include "semantic.h"
 #include "codec.h"
+#include "audio.h"
 #include "conv1d.h"
 #include "ctx.h"
 #include "gpt.h"
@@ -470,6 +471,39 @@ int idxtts_repcodec_quantize(idxtts_ctx* ctx, const float* x, int B, int T, long
   auto* m = dynamic_cast<RepCodecModel*>(ctx->model.get());
   IDX_CHECK(m, "not a semantic-codec context");
   return m->quantize(x, B, T, indices, quantized, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+  API_END
+}
+
+int idxtts_melspec_create(const idxtts_melspec_config* cfg, idxtts_ctx** out) {
+  API_BEGIN
+  IDX_CHECK(cfg && out, "null pointer");
+  std::unique_ptr<idxtts_ctx> ctx(new idxtts_ctx());
+  ctx->model.reset(new MelSpecModel(*cfg));
+  *out = ctx.release();
+  return 0;
+  API_END
+}
+
+int idxtts_melspec_frames(const idxtts_ctx* ctx, int n_samples) {
+  if (!ctx || n_samples <= 0) return 0;
+  auto* m = dynamic_cast<const MelSpecModel*>(ctx->model.get());
+  return m ? m->frames(n_samples) : 0;
+}
+
+size_t idxtts_melspec_workspace_bytes(const idxtts_ctx* ctx, int B, int n_samples) {
+  if (!ctx || !ctx->finalized || B <= 0 || n_samples <= 0) return 0;
+  auto* m = dynamic_cast<const MelSpecModel*>(ctx->model.get());
+  return m ? m->workspace_bytes(B, n_samples) : 0;
+}
+
+int idxtts_melspec_forward(idxtts_ctx* ctx, const float* audio, int B, int n_samples, float* mel, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+  API_BEGIN
+  IDX_CHECK(ctx, "null ctx");
+  IDX_CHECK(ctx->finalized, "context not finalized");
+  auto* m = dynamic_cast<MelSpecModel*>(ctx->model.get());
+  IDX_CHECK(m, "not a mel-spectrogram context");
+  return m->forward(audio, B, n_samples, mel, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
   API_END
 }
 

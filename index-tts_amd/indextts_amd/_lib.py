@@ -28,6 +28,7 @@ SYMBOLS = [
     "idxtts_s2mel_estimator", "idxtts_s2mel_regulate", "idxtts_cond_create", "idxtts_cond_workspace_bytes", "idxtts_cond_forward", "idxtts_emovec_merge",
     "idxtts_w2vbert_create", "idxtts_w2vbert_workspace_bytes", "idxtts_w2vbert_forward",
     "idxtts_repcodec_create", "idxtts_repcodec_workspace_bytes", "idxtts_repcodec_quantize",
+    "idxtts_melspec_create", "idxtts_melspec_frames", "idxtts_melspec_workspace_bytes", "idxtts_melspec_forward",
 ]
 
 
@@ -63,6 +64,10 @@ class W2VBertConfigC(ctypes.Structure):      # idxtts_w2vbert_config (include/id
 
 class RepCodecConfigC(ctypes.Structure):     # idxtts_repcodec_config (include/idxtts.h)
     _fields_ = [(n, c_int) for n in ("hidden_size", "codebook_size", "codebook_dim", "vocos_dim", "vocos_intermediate_dim", "vocos_num_layers")]
+
+
+class MelSpecConfigC(ctypes.Structure):      # idxtts_melspec_config (include/idxtts.h)
+    _fields_ = [(n, c_int) for n in ("n_fft", "hop_size", "win_size", "num_mels")]
 
 
 class BeamC(ctypes.Structure):               # idxtts_beam (include/idxtts.h)
@@ -153,6 +158,11 @@ def load() -> ctypes.CDLL:
     lib.idxtts_cond_workspace_bytes.restype = c_size_t
     lib.idxtts_cond_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.idxtts_emovec_merge.argtypes = [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]
+    lib.idxtts_melspec_create.argtypes = [POINTER(MelSpecConfigC), POINTER(c_void_p)]
+    lib.idxtts_melspec_frames.argtypes = [c_void_p, c_int]
+    lib.idxtts_melspec_workspace_bytes.argtypes = [c_void_p, c_int, c_int]
+    lib.idxtts_melspec_workspace_bytes.restype = c_size_t
+    lib.idxtts_melspec_forward.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.idxtts_repcodec_create.argtypes = [POINTER(RepCodecConfigC), POINTER(c_void_p)]
     lib.idxtts_repcodec_workspace_bytes.argtypes = [c_void_p, c_int, c_int]
     lib.idxtts_repcodec_workspace_bytes.restype = c_size_t

@@ -764,6 +764,34 @@ def make_repcodec():
     print("repcodec.npz", {k: v.shape for k, v in out.items()})
 
 
+def make_melspec():
+    """Prompt log-mel fixtures from the reference's own `mel_spectrogram` (s2mel/modules/audio.py:45-83) with infer_v2.py's arguments.
+    `librosa.filters.mel`, which that module imports at load time, is absent in this image: it is supplied by
+    transformers.audio_utils.mel_filter_bank(norm="slaney", mel_scale="slaney") (a third-party port of the librosa function)."""
+    from transformers.audio_utils import mel_filter_bank
+    _install_placeholders()
+
+    def librosa_mel(sr, n_fft, n_mels, fmin, fmax):
+        fmax = sr / 2 if fmax is None else fmax
+        return mel_filter_bank(num_frequency_bins=n_fft // 2 + 1, num_mel_filters=n_mels, min_frequency=fmin, max_frequency=fmax,
+                               sampling_rate=sr, norm="slaney", mel_scale="slaney").T.astype(np.float32)
+
+    sys.modules["librosa.filters"].mel = librosa_mel
+    sys.modules["librosa"].filters = sys.modules["librosa.filters"]
+    from indextts.s2mel.modules.audio import mel_spectrogram
+    from indextts_amd import synth
+    n = 22050 + 333
+    t = np.arange(n) / 22050.0
+    y = np.stack([0.4 * np.sin(2 * np.pi * 310 * t) + 0.2 * np.sin(2 * np.pi * 2400 * t + 1.0) + 0.05 * synth.uniform("golden/mel/a", (n,), 1.0),
+                  0.3 * np.sin(2 * np.pi * (150 + 800 * t) * t) + 0.02 * synth.uniform("golden/mel/b", (n,), 1.0)]).astype(np.float32)
+    with torch.no_grad():
+        mel = mel_spectrogram(torch.from_numpy(y), n_fft=1024, num_mels=80, sampling_rate=22050, hop_size=256, win_size=1024, fmin=0, fmax=None,
+                              center=False)
+    out = {"audio": y, "mel": mel.numpy(), "mel_basis": librosa_mel(22050, 1024, 80, 0, None)}
+    np.savez_compressed(os.path.join(HERE, "melspec.npz"), **out)
+    print("melspec.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     torch.manual_seed(0)
@@ -784,3 +812,5 @@ if __name__ == "__main__":
         make_segments()
     if which in ("repcodec", "all"):
         make_repcodec()
+    if which in ("melspec", "all"):
+        make_melspec()
