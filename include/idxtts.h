@@ -295,6 +295,21 @@ size_t idxtts_melspec_workspace_bytes(const idxtts_ctx* ctx, int B, int n_sample
 int idxtts_melspec_forward(idxtts_ctx* ctx, const float* audio, int B, int n_samples, float* mel, void* workspace, size_t workspace_bytes,
                            void* stream);
 
+/* ---- CAMPPlus speaker encoder: the global style vector of the prompt (reference: `style = self.campplus_model(feat.unsqueeze(0))`,
+ * infer_v2.py:251-257, 641-647; CAMPPlus, s2mel/modules/campplus/DTDNN.py:62-140, layers.py) ------------------------------
+ * State-dict keys: CAMPPlus's own ("head.*", "xvector.*": campplus_cn_common.bin), BatchNorm running statistics included
+ * (inference mode; "num_batches_tracked" entries are ignored). */
+typedef struct idxtts_campplus_config {
+  int feat_dim, embedding_size;                        /* 80, 192 */
+  int m_channels, growth_rate, bn_size, init_channels; /* 32, 32, 4, 128 */
+  int num_blocks;                                      /* 3 */
+  int block_layers[4], block_dilation[4];              /* {12, 24, 16}, {1, 2, 2} (kernel 3) */
+} idxtts_campplus_config;
+int idxtts_campplus_create(const idxtts_campplus_config* cfg, idxtts_ctx** out);
+size_t idxtts_campplus_workspace_bytes(const idxtts_ctx* ctx, int T);
+/* feat: device [B][T][feat_dim] (Kaldi fbank minus its mean over time); style: device [B][embedding_size]. */
+int idxtts_campplus_forward(idxtts_ctx* ctx, const float* feat, int B, int T, float* style, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- s2mel stage (reference: infer_v2.py:835-856; MyModel commons.py:390-420) -------------------------
  * State-dict keys: "cfm.estimator.*", "length_regulator.*", "gpt_layer.{0,1,2}.*" (s2mel.pth['net'][...], weight-norm
  * layers folded to plain ".weight"), "semantic_codec.quantizer.quantizers.0.{codebook.weight,out_project.weight,out_project.bias}",

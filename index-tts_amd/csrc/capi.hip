@@ -8,6 +8,7 @@
 #include "semantic.h"
 #include "codec.h"
 #include "audio.h"
+#include "campplus.h"
 #include "conv1d.h"
 #include "ctx.h"
 #include "gpt.h"
@@ -504,6 +505,32 @@ int idxtts_melspec_forward(idxtts_ctx* ctx, const float* audio, int B, int n_sam
   auto* m = dynamic_cast<MelSpecModel*>(ctx->model.get());
   IDX_CHECK(m, "not a mel-spectrogram context");
   return m->forward(audio, B, n_samples, mel, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+  API_END
+}
+
+int idxtts_campplus_create(const idxtts_campplus_config* cfg, idxtts_ctx** out) {
+  API_BEGIN
+  IDX_CHECK(cfg && out, "null pointer");
+  std::unique_ptr<idxtts_ctx> ctx(new idxtts_ctx());
+  ctx->model.reset(new CamPPlusModel(*cfg));
+  *out = ctx.release();
+  return 0;
+  API_END
+}
+
+size_t idxtts_campplus_workspace_bytes(const idxtts_ctx* ctx, int T) {
+  if (!ctx || !ctx->finalized || T < 8) return 0;
+  auto* m = dynamic_cast<const CamPPlusModel*>(ctx->model.get());
+  return m ? m->workspace_bytes(T) : 0;
+}
+
+int idxtts_campplus_forward(idxtts_ctx* ctx, const float* feat, int B, int T, float* style, void* workspace, size_t workspace_bytes, void* stream) {
+  API_BEGIN
+  IDX_CHECK(ctx, "null ctx");
+  IDX_CHECK(ctx->finalized, "context not finalized");
+  auto* m = dynamic_cast<CamPPlusModel*>(ctx->model.get());
+  IDX_CHECK(m, "not a CAMPPlus context");
+  return m->forward(feat, B, T, style, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
   API_END
 }
 

@@ -5,7 +5,7 @@
 namespace idxtts {
 
 enum GemmAct { ACT_NONE = 0, ACT_GELU_NEW = 1, ACT_SILU = 2, ACT_SWIGLU = 3, ACT_MISH = 4, ACT_GATE = 5 /* tanh(a)*sigmoid(b), packed like SWIGLU */,
-               ACT_GELU_ERF = 6 /* nn.GELU(): exact fp32 GEMM only */ };
+               ACT_GELU_ERF = 6 /* nn.GELU(): exact fp32 GEMM only */, ACT_RELU = 7 /* exact fp32 GEMM only */ };
 
 struct LinearWeights {      // device-resident, packed for the MFMA B operand
   const float* wp = nullptr;   // [ceil(N/32)][ceil(K/16)][g2][h2][j32][4]

@@ -36,6 +36,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
   if (act == ACT_SILU) return v / (1.0f + expf(-v));
   if (act == ACT_GELU_ERF) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+  if (act == ACT_RELU) return fmaxf(v, 0.0f);
   if (act == ACT_MISH) {   // x * tanh(softplus(x)), softplus threshold 20 as torch
     const float sp = v > 20.0f ? v : log1pf(expf(v));
     return v * tanhf(sp);

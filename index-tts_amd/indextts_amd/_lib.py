@@ -29,6 +29,7 @@ SYMBOLS = [
     "idxtts_w2vbert_create", "idxtts_w2vbert_workspace_bytes", "idxtts_w2vbert_forward",
     "idxtts_repcodec_create", "idxtts_repcodec_workspace_bytes", "idxtts_repcodec_quantize",
     "idxtts_melspec_create", "idxtts_melspec_frames", "idxtts_melspec_workspace_bytes", "idxtts_melspec_forward",
+    "idxtts_campplus_create", "idxtts_campplus_workspace_bytes", "idxtts_campplus_forward",
 ]
 
 
@@ -68,6 +69,11 @@ class RepCodecConfigC(ctypes.Structure):     # idxtts_repcodec_config (include/i
 
 class MelSpecConfigC(ctypes.Structure):      # idxtts_melspec_config (include/idxtts.h)
     _fields_ = [(n, c_int) for n in ("n_fft", "hop_size", "win_size", "num_mels")]
+
+
+class CamPPlusConfigC(ctypes.Structure):     # idxtts_campplus_config (include/idxtts.h)
+    _fields_ = [(n, c_int) for n in ("feat_dim", "embedding_size", "m_channels", "growth_rate", "bn_size", "init_channels", "num_blocks")] + [
+        ("block_layers", c_int * 4), ("block_dilation", c_int * 4)]
 
 
 class BeamC(ctypes.Structure):               # idxtts_beam (include/idxtts.h)
@@ -158,6 +164,10 @@ def load() -> ctypes.CDLL:
     lib.idxtts_cond_workspace_bytes.restype = c_size_t
     lib.idxtts_cond_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.idxtts_emovec_merge.argtypes = [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]
+    lib.idxtts_campplus_create.argtypes = [POINTER(CamPPlusConfigC), POINTER(c_void_p)]
+    lib.idxtts_campplus_workspace_bytes.argtypes = [c_void_p, c_int]
+    lib.idxtts_campplus_workspace_bytes.restype = c_size_t
+    lib.idxtts_campplus_forward.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.idxtts_melspec_create.argtypes = [POINTER(MelSpecConfigC), POINTER(c_void_p)]
     lib.idxtts_melspec_frames.argtypes = [c_void_p, c_int]
     lib.idxtts_melspec_workspace_bytes.argtypes = [c_void_p, c_int, c_int]

@@ -205,3 +205,17 @@ class RepCodecConfig:
     @staticmethod
     def tiny() -> "RepCodecConfig":
         return RepCodecConfig(hidden_size=64, codebook_size=57, codebook_dim=4, vocos_dim=32, vocos_intermediate_dim=48, vocos_num_layers=2)
+
+
+@dataclass(frozen=True)
+class CamPPlusConfig:
+    """CAMPPlus(feat_dim=80, embedding_size=192) (infer_v2.py:254; DTDNN.py:62-140: growth 32, bn_size 4, 128 initial channels,
+    dense blocks of 12 / 24 / 16 layers with kernel 3 and dilation 1 / 2 / 2)."""
+    feat_dim: int = 80
+    embedding_size: int = 192
+    m_channels: int = 32
+    growth_rate: int = 32
+    bn_size: int = 4
+    init_channels: int = 128
+    block_layers: tuple = (12, 24, 16)
+    block_dilation: tuple = (1, 2, 2)

@@ -299,6 +299,21 @@ class IndexTTS2:
         if emo_vector is not None or use_emo_text:
             raise NotImplementedError("emo_vector / emo_text routing (emotion matrices, Qwen classifier: infer_v2.py:586-615, 668-679) "
                                       "happens upstream of this path: fold the result into PromptConditioning.emo_vec")
+        from .prompt import PromptAudio
+        if isinstance(spk_audio_prompt, PromptAudio):
+            # audio path: w2v-bert / semantic codec / CAMPPlus / mel / length regulator on the GPU (indextts_amd/prompt.py), cached per
+            # prompt object like the reference's cache_spk_cond / cache_emo_cond (infer_v2.py:618, 681)
+            enc = getattr(self, "prompt_encoders", None)
+            if enc is None:
+                raise RuntimeError("attach the audio-side encoders first: tts.prompt_encoders = PromptEncoders(w2vbert_sd, codec_sd, campplus_sd, tts.s2mel)")
+            if emo_audio_prompt is not None and not isinstance(emo_audio_prompt, PromptAudio):
+                raise NotImplementedError("with an audio speaker prompt the emotion prompt must be a PromptAudio too")
+            akey = (id(spk_audio_prompt), id(emo_audio_prompt))
+            if getattr(self, "_audio_cache_key", None) != akey:
+                self._audio_cache = enc.encode(spk_audio_prompt, emo_audio_prompt)
+                self._audio_cache_key = akey
+                self._audio_cache_refs = (spk_audio_prompt, emo_audio_prompt)
+            spk_audio_prompt, emo_audio_prompt = self._audio_cache, None
         if isinstance(spk_audio_prompt, PromptFeatures):
             # prompt-feature path: conformer + perceiver + emotion vector on the GPU, cached per (prompt, emotion prompt, alpha) like
             # the reference caches its prompt features (infer_v2.py:618, 681)
@@ -317,8 +332,8 @@ class IndexTTS2:
         elif emo_audio_prompt is not None:
             raise NotImplementedError("with a ready PromptConditioning the emotion prompt is already folded into emo_vec")
         if not isinstance(spk_audio_prompt, PromptConditioning):
-            raise NotImplementedError("audio-side prompt encoders (w2v-bert / RepCodec / CAMPPlus / mel) are outside this hot path "
-                                      "(SURVEY.md §8f rank 1): pass PromptFeatures or a PromptConditioning")
+            raise NotImplementedError("pass a PromptAudio (resampled waveforms; needs tts.prompt_encoders), PromptFeatures or a PromptConditioning: "
+                                      "reading and resampling audio files is left to the caller (librosa / torchaudio are not in this image)")
         segs = text if (len(text) and isinstance(text[0], (list, tuple, np.ndarray, torch.Tensor))) else [text]
         segs = [torch.as_tensor(s, dtype=torch.long).reshape(1, -1) for s in segs]
         if not segs or any(s.numel() == 0 for s in segs):

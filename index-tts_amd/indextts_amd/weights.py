@@ -16,7 +16,7 @@ from typing import Dict
 import numpy as np
 
 from . import synth
-from .config import BigVGANConfig, GPTConfig, RepCodecConfig, S2MelConfig, W2VBertConfig
+from .config import BigVGANConfig, CamPPlusConfig, GPTConfig, RepCodecConfig, S2MelConfig, W2VBertConfig
 
 Weights = Dict[str, np.ndarray]
 
@@ -343,4 +343,66 @@ def synth_repcodec_weights(cfg: RepCodecConfig, tag: str = "repcodec") -> Weight
     w[f"{q}.out_project.weight"] = synth.fan_in_uniform(f"{tag}/{q}.out_project.weight", (Hs, cd, 1), cd, 1.0)
     u(f"{q}.out_project.bias", (Hs,), 0.1)
     u(f"{q}.codebook.weight", (cfg.codebook_size, cd), 1.0)
+    return w
+
+
+# --------------------------------------------------------------------------------------
+# CAMPPlus (s2mel/modules/campplus/DTDNN.py:62-140; campplus_cn_common.bin's key layout)
+# --------------------------------------------------------------------------------------
+def synth_campplus_weights(cfg: CamPPlusConfig = CamPPlusConfig(), tag: str = "campplus") -> Weights:
+    """Keys / shapes of `CAMPPlus(feat_dim, embedding_size).state_dict()` (BatchNorm running statistics included; the
+    `num_batches_tracked` counters are left out: load_state_dict(strict=False) on the reference side)."""
+    w: Weights = {}
+    mc, G, BNC, IC = cfg.m_channels, cfg.growth_rate, cfg.bn_size * cfg.growth_rate, cfg.init_channels
+
+    def u(name, shape, scale, offset=0.0):
+        w[name] = synth.uniform(f"{tag}/{name}", shape, scale, offset)
+
+    def bn(name, n, affine=True):
+        if affine:
+            u(f"{name}.weight", (n,), 0.3, 1.0)
+            u(f"{name}.bias", (n,), 0.2)
+        u(f"{name}.running_mean", (n,), 0.3)
+        u(f"{name}.running_var", (n,), 0.4, 1.0)
+
+    def conv(name, shape, fan_in, gain):
+        w[f"{name}.weight"] = synth.fan_in_uniform(f"{tag}/{name}.weight", shape, fan_in, gain)
+
+    conv("head.conv1", (mc, 1, 3, 3), 9, 1.6)
+    bn("head.bn1", mc)
+    for l in (1, 2):
+        for j in (0, 1):
+            p = f"head.layer{l}.{j}"
+            conv(f"{p}.conv1", (mc, mc, 3, 3), mc * 9, 1.5)
+            bn(f"{p}.bn1", mc)
+            conv(f"{p}.conv2", (mc, mc, 3, 3), mc * 9, 1.2)
+            bn(f"{p}.bn2", mc)
+            if j == 0:
+                conv(f"{p}.shortcut.0", (mc, mc, 1, 1), mc, 1.0)
+                bn(f"{p}.shortcut.1", mc)
+    conv("head.conv2", (mc, mc, 3, 3), mc * 9, 1.5)
+    bn("head.bn2", mc)
+    ch = mc * (cfg.feat_dim // 8)
+    conv("xvector.tdnn.linear", (IC, ch, 5), ch * 5, 1.5)
+    bn("xvector.tdnn.nonlinear.batchnorm", IC)
+    ch = IC
+    for bi, n_layers in enumerate(cfg.block_layers):
+        for i in range(n_layers):
+            p = f"xvector.block{bi + 1}.tdnnd{i + 1}"
+            cin = ch + i * G
+            bn(f"{p}.nonlinear1.batchnorm", cin)
+            conv(f"{p}.linear1", (BNC, cin, 1), cin, 1.6)
+            bn(f"{p}.nonlinear2.batchnorm", BNC)
+            conv(f"{p}.cam_layer.linear_local", (G, BNC, 3), BNC * 3, 1.6)
+            conv(f"{p}.cam_layer.linear1", (BNC // 2, BNC, 1), BNC, 1.4)
+            u(f"{p}.cam_layer.linear1.bias", (BNC // 2,), 0.2)
+            conv(f"{p}.cam_layer.linear2", (G, BNC // 2, 1), BNC // 2, 1.4)
+            u(f"{p}.cam_layer.linear2.bias", (G,), 0.2)
+        ch += n_layers * G
+        bn(f"xvector.transit{bi + 1}.nonlinear.batchnorm", ch)
+        conv(f"xvector.transit{bi + 1}.linear", (ch // 2, ch, 1), ch, 1.5)
+        ch //= 2
+    bn("xvector.out_nonlinear.batchnorm", ch)
+    conv("xvector.dense.linear", (cfg.embedding_size, 2 * ch, 1), 2 * ch, 1.2)
+    bn("xvector.dense.nonlinear.batchnorm", cfg.embedding_size, affine=False)
     return w

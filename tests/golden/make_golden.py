@@ -792,6 +792,31 @@ def make_melspec():
     print("melspec.npz", {k: v.shape for k, v in out.items()})
 
 
+def make_campplus():
+    """Style-vector fixtures from the reference's own CAMPPlus class (s2mel/modules/campplus/DTDNN.py) in eval mode carrying the
+    synthetic weights, at the real configuration (feat_dim 80, embedding 192): a 2.3 s and a 0.6 s feature sequence (three 100-frame
+    context segments, the last one partial; and a single partial one), plus the FCM head's output for the shorter one."""
+    _install_placeholders()
+    from indextts.s2mel.modules.campplus.DTDNN import CAMPPlus
+    from indextts_amd import synth, weights
+    from indextts_amd.config import CamPPlusConfig
+    cfg = CamPPlusConfig()
+    w = weights.synth_campplus_weights(cfg, tag="golden/campplus")
+    m = CAMPPlus(feat_dim=cfg.feat_dim, embedding_size=cfg.embedding_size).eval()
+    missing, unexpected = m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing, unexpected)
+    out = {}
+    with torch.no_grad():
+        for tag, T in (("a", 461), ("b", 61)):
+            feat = torch.from_numpy(synth.uniform(f"golden/campplus/feat_{tag}", (1, T, cfg.feat_dim), 2.0))
+            feat = feat - feat.mean(dim=1, keepdim=True)                       # infer_v2.py:646
+            out[f"feat_{tag}"] = feat.numpy()
+            out[f"style_{tag}"] = m(feat).numpy()
+        out["fcm_b"] = m.head(torch.from_numpy(out["feat_b"]).permute(0, 2, 1)).numpy()
+    np.savez_compressed(os.path.join(HERE, "campplus.npz"), **out)
+    print("campplus.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     torch.manual_seed(0)
@@ -814,3 +839,5 @@ if __name__ == "__main__":
         make_repcodec()
     if which in ("melspec", "all"):
         make_melspec()
+    if which in ("campplus", "all"):
+        make_campplus()
