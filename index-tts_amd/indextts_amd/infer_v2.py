@@ -76,7 +76,7 @@ class PromptConditioning:
             t("ref_mel", (1, cfg.s2mel.in_channels, prompt_frames), 2.6, -4.0))
 
     @staticmethod
-    def from_features(gpt: UnifiedVoice, feats: "PromptFeatures", emo_alpha: float = 1.0) -> "PromptConditioning":
+    def from_features(gpt: UnifiedVoice, feats: "PromptFeatures", emo_alpha: float = 1.0, emo_mix=None) -> "PromptConditioning":
         """The per-prompt half of the reference's segment loop, once per prompt instead of once per segment:
         `merge_emovec(spk_cond_emb, emo_cond_emb, ..., alpha=emo_alpha)` (infer_v2.py:748-754) and the `get_conditioning` call
         inside `inference_speech` (model_v2.py:819), on the HIP conditioning encoders.  The "lengths" are the reference's:
@@ -86,6 +86,9 @@ class PromptConditioning:
         emo = spk if feats.emo_cond_emb is None else feats.emo_cond_emb.to(dev, torch.float32)
         ln_s, ln_e = torch.tensor([spk.shape[-1]]), torch.tensor([emo.shape[-1]])
         emovec = gpt.merge_emovec(spk, emo, ln_s, ln_e, alpha=emo_alpha)
+        if emo_mix is not None:                     # (emovec_mat [1,d], weight_vector): infer_v2.py:756-757
+            emovec_mat, weight_vector = emo_mix
+            emovec = emovec_mat.to(dev, torch.float32) + (1 - torch.sum(weight_vector.to(dev, torch.float32))) * emovec
         latent = gpt.get_conditioning(spk.transpose(1, 2), ln_s)
         return PromptConditioning(latent, emovec, feats.style, feats.prompt_condition, feats.ref_mel)
 
@@ -285,6 +288,30 @@ class IndexTTS2:
         except IndexError:
             return None
 
+    def set_emotion_matrices(self, emo_matrix: torch.Tensor, spk_matrix: torch.Tensor, emo_num):
+        """feat2.pt / feat1.pt and cfg.emo_num (infer_v2.py:281-289): the per-emotion banks the emo_vector mode mixes from."""
+        emo_num = list(emo_num)
+        self.emo_num = emo_num
+        self.emo_matrix = torch.split(torch.as_tensor(emo_matrix).to(self.device, torch.float32), emo_num)
+        self.spk_matrix = torch.split(torch.as_tensor(spk_matrix).to(self.device, torch.float32), emo_num)
+
+    def emotion_vector_mix(self, style: torch.Tensor, emo_vector, use_random: bool = False):
+        """infer_v2.py:668-679: per emotion pick the bank entry whose speaker vector is closest (cosine) to this prompt's style -- or a
+        random one --, weight by emo_vector.  Returns (emovec_mat [1,d], weight_vector)."""
+        if not hasattr(self, "emo_matrix"):
+            raise RuntimeError("emo_vector needs the emotion banks: call set_emotion_matrices(emo_matrix, spk_matrix, emo_num) first")
+        if len(emo_vector) != len(self.emo_num):
+            raise ValueError(f"emo_vector needs {len(self.emo_num)} weights")
+        import random
+        weight_vector = torch.tensor(emo_vector, device=self.device, dtype=torch.float32)
+        style = style.to(self.device, torch.float32)
+        if use_random:
+            index = [random.randint(0, x - 1) for x in self.emo_num]
+        else:
+            index = [int(torch.argmax(torch.nn.functional.cosine_similarity(style, tmp, dim=1))) for tmp in self.spk_matrix]     # find_most_similar_cosine
+        emo_matrix = torch.cat([tmp[i].unsqueeze(0) for i, tmp in zip(index, self.emo_matrix)], 0)
+        return torch.sum(weight_vector.unsqueeze(1) * emo_matrix, 0).unsqueeze(0), weight_vector
+
     def infer_generator(self, spk_audio_prompt, text, output_path, emo_audio_prompt=None, emo_alpha=1.0, emo_vector=None,
                         use_emo_text=False, emo_text=None, use_random=False, interval_silence=200, verbose=False,
                         max_text_tokens_per_segment=120, stream_return=False, quick_streaming_tokens=0, return_audio=False,
@@ -296,9 +323,15 @@ class IndexTTS2:
         if isinstance(text, str):
             raise NotImplementedError("the text front-end (tokenizer/segmenter) is outside this hot path (SURVEY.md §8f rank 3): "
                                       "pass token ids")
-        if emo_vector is not None or use_emo_text:
-            raise NotImplementedError("emo_vector / emo_text routing (emotion matrices, Qwen classifier: infer_v2.py:586-615, 668-679) "
-                                      "happens upstream of this path: fold the result into PromptConditioning.emo_vec")
+        if use_emo_text:
+            raise NotImplementedError("emo_text routing (the Qwen emotion classifier, infer_v2.py:590-598) happens upstream of this path: "
+                                      "pass its result as emo_vector")
+        if emo_vector is not None:
+            emo_audio_prompt = None                                                                  # infer_v2.py:586-589
+            scale = max(0.0, min(1.0, emo_alpha))                                                    # 600-608
+            if scale != 1.0:
+                emo_vector = [int(x * scale * 10000) / 10000 for x in emo_vector]
+            emo_alpha = 1.0                                                                          # 610-615: the speaker prompt serves
         from .prompt import PromptAudio
         if isinstance(spk_audio_prompt, PromptAudio):
             # audio path: w2v-bert / semantic codec / CAMPPlus / mel / length regulator on the GPU (indextts_amd/prompt.py), cached per
@@ -323,14 +356,15 @@ class IndexTTS2:
                     raise NotImplementedError("emo_audio_prompt must be a PromptFeatures or the emotion prompt's [1,T,1024] features")
                 emo_emb = emo_audio_prompt.spk_cond_emb if isinstance(emo_audio_prompt, PromptFeatures) else emo_audio_prompt
                 feats = PromptFeatures(feats.spk_cond_emb, feats.style, feats.prompt_condition, feats.ref_mel, emo_emb)
-            key = (id(spk_audio_prompt), id(emo_audio_prompt), float(emo_alpha))
-            if getattr(self, "_cond_cache_key", None) != key:
-                self._cond_cache = PromptConditioning.from_features(self.gpt, feats, emo_alpha=emo_alpha)
+            key = (id(spk_audio_prompt), id(emo_audio_prompt), float(emo_alpha), None if emo_vector is None else (tuple(emo_vector), bool(use_random)))
+            if getattr(self, "_cond_cache_key", None) != key or (emo_vector is not None and use_random):
+                mix = None if emo_vector is None else self.emotion_vector_mix(feats.style, emo_vector, use_random=use_random)
+                self._cond_cache = PromptConditioning.from_features(self.gpt, feats, emo_alpha=emo_alpha, emo_mix=mix)
                 self._cond_cache_key = key
                 self._cond_cache_refs = (spk_audio_prompt, emo_audio_prompt)     # keep the ids alive
             spk_audio_prompt = self._cond_cache
-        elif emo_audio_prompt is not None:
-            raise NotImplementedError("with a ready PromptConditioning the emotion prompt is already folded into emo_vec")
+        elif emo_audio_prompt is not None or emo_vector is not None:
+            raise NotImplementedError("with a ready PromptConditioning the emotion prompt / vector is already folded into emo_vec")
         if not isinstance(spk_audio_prompt, PromptConditioning):
             raise NotImplementedError("pass a PromptAudio (resampled waveforms; needs tts.prompt_encoders), PromptFeatures or a PromptConditioning: "
                                       "reading and resampling audio files is left to the caller (librosa / torchaudio are not in this image)")

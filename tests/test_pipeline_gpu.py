@@ -148,6 +148,46 @@ def test_infer_from_prompt_features_hoists_the_conditioning(device):
     assert c.shape != a.shape or not np.array_equal(a, c)
 
 
+def test_infer_emo_vector_mixes_the_emotion_banks(device):
+    """emo_vector (infer_v2.py:586-615, 668-679, 756-757): the closest bank entries by cosine similarity to the prompt's style, weighted,
+    mixed with (1 - sum(w)) of the prompt's own emotion vector; emo_alpha scales the weights (truncated to 4 decimals)."""
+    from indextts_amd.infer_v2 import IndexTTS2, PromptConditioning, PromptFeatures
+    cfg = PipelineConfig.tiny()
+    wg = weights.synth_gpt_weights(cfg.gpt, tag="t/pipe/gpt")
+    wg.update(weights.synth_gpt_cond_weights(cfg.gpt, tag="t/pipe/gpt"))
+    wg["mel_head.bias"] = wg["mel_head.bias"].copy()
+    wg["mel_head.bias"][cfg.gpt.stop_mel_token] = -1e4
+    tts = IndexTTS2.from_state_dicts(cfg, wg, weights.synth_s2mel_weights(cfg.s2mel, tag="t/pipe/s2mel"),
+                                     weights.synth_bigvgan_weights(cfg.bigvgan, tag="t/pipe/voc"), device=device)
+    feats = PromptFeatures.synthetic(cfg, prompt_frames=11, feat_frames=31, tag="t/pipe/feats")
+    emo_num = [3, 2, 4]
+    d = cfg.gpt.model_dim
+    emo_matrix = torch.from_numpy(synth.uniform("t/pipe/emo_matrix", (sum(emo_num), d), 0.5))
+    spk_matrix = torch.from_numpy(synth.uniform("t/pipe/spk_matrix", (sum(emo_num), cfg.s2mel.style_dim), 1.0))
+    seg = synth.integers("t/pipe/eseg", (1, 6), 2, cfg.gpt.number_text_tokens).tolist()
+    G = dict(do_sample=False, num_beams=1, max_mel_tokens=12)
+    import warnings
+    warnings.simplefilter("ignore")
+    with pytest.raises(RuntimeError):
+        tts.infer(feats, seg, None, emo_vector=[0.2, 0.1, 0.3], **G)
+    tts.set_emotion_matrices(emo_matrix, spk_matrix, emo_num)
+    torch.manual_seed(2)
+    _, a = tts.infer(feats, seg, None, emo_vector=[0.2, 0.1, 0.3], emo_alpha=0.5, **G)
+    # the same mix by hand
+    w = torch.tensor([int(x * 0.5 * 10000) / 10000 for x in (0.2, 0.1, 0.3)])
+    idx = [int(torch.argmax(torch.nn.functional.cosine_similarity(feats.style, m, dim=1))) for m in torch.split(spk_matrix, emo_num)]
+    mat = torch.stack([m[i] for i, m in zip(idx, torch.split(emo_matrix, emo_num))])
+    base = PromptConditioning.from_features(tts.gpt, feats, emo_alpha=1.0)
+    emovec = (w[:, None] * mat).sum(0, keepdim=True).to(device) + (1 - w.sum()) * base.emo_vec
+    cond = PromptConditioning(base.spk_cond_latent, emovec, base.style, base.prompt_condition, base.ref_mel)
+    torch.manual_seed(2)
+    _, b = tts.infer(cond, seg, None, **G)
+    assert np.array_equal(a, b)
+    torch.manual_seed(2)
+    _, c = tts.infer(feats, seg, None, **G)
+    assert not np.array_equal(a, c)
+
+
 def test_infer_streaming_contract(device):
     """stream_return (infer_v2.py:547-555, 874-886): a generator that yields, per segment, the segment's waveform ([1, n] float32
     on the CPU, scaled and clamped) and then the inter-segment silence -- and nothing else; joined, the chunks are the
