@@ -321,8 +321,15 @@ class IndexTTS2:
         if stream_return and return_audio:
             raise ValueError("stream_return and return_audio are mutually exclusive")                # infer_v2.py:575-576
         if isinstance(text, str):
-            raise NotImplementedError("the text front-end (tokenizer/segmenter) is outside this hot path (SURVEY.md §8f rank 3): "
-                                      "pass token ids")
+            # text front-end (infer_v2.py:697-704): tokenize, split into segments, ids.  The tokenizer (indextts_amd/tokenizer.py) needs
+            # the checkpoint's bpe.model and, for real text, the reference's normaliser (WeTextProcessing): both absent offline.
+            tok = getattr(self, "tokenizer", None)
+            if tok is None:
+                raise RuntimeError("a str text needs the tokenizer: tts.tokenizer = TextTokenizer('checkpoints/bpe.model', normalizer); "
+                                   "or pass token-id segments")
+            tokens = tok.tokenize(text)
+            text = [tok.convert_tokens_to_ids(seg) for seg in tok.split_segments(tokens, max_text_tokens_per_segment,
+                                                                                 quick_streaming_tokens=quick_streaming_tokens)]
         if use_emo_text:
             raise NotImplementedError("emo_text routing (the Qwen emotion classifier, infer_v2.py:590-598) happens upstream of this path: "
                                       "pass its result as emo_vector")

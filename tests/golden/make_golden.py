@@ -817,6 +817,46 @@ def make_campplus():
     print("campplus.npz", {k: v.shape for k, v in out.items()})
 
 
+def make_tokenizer():
+    """Tokenizer fixtures from the reference's own TextTokenizer (indextts/utils/front.py:231-343, normalizer=None: WeTextProcessing is
+    absent) over a small SentencePiece BPE model trained here on a synthetic corpus and committed next to the fixture
+    (tests/golden/tiny_bpe.model): tokens, ids, decoded strings and the segments of `split_segments`."""
+    import io
+    import json
+    import sentencepiece as spm
+    _install_placeholders()
+    from indextts.utils.front import TextTokenizer
+    corpus = ["the quick brown fox jumps over the lazy dog.", "hello world, this is a test of the tokenizer!", "你好世界, 这是一个测试。",
+              "今天天气很好, we are going to the park.", "what's the matter? it's nothing - really.", "一二三四五六七八九十, 百千万。",
+              "speech synthesis with large language models is fun.", "语音合成 is what we do here, 每天都是。"] * 40
+    model = io.BytesIO()
+    spm.SentencePieceTrainer.train(sentence_iterator=iter([tokenize_up(c) for c in corpus]), model_writer=model, vocab_size=180, model_type="bpe",
+                                   character_coverage=1.0, bos_id=0, eos_id=1, unk_id=2, pad_id=-1, user_defined_symbols=[])
+    path = os.path.join(HERE, "tiny_bpe.model")
+    with open(path, "wb") as f:
+        f.write(model.getvalue())
+    tok = TextTokenizer(path, normalizer=None)
+    texts = ["Hello world, this is a test!", "你好世界是 hello world 的中文", "What's the matter? It's nothing - really. 今天天气很好。", "a", " ", "",
+             "the quick brown fox, the lazy dog. speech synthesis is fun! 一二三, 四五六。 what's next? nothing."]
+    cases = []
+    for t in texts:
+        tokens = tok.tokenize(t)
+        ids = tok.convert_tokens_to_ids(tokens)
+        cases.append({"text": t, "tokens": tokens, "ids": ids, "encode": tok.encode(t), "decoded": tok.decode(ids) if ids else "",
+                      "decoded_lower": tok.decode(ids, do_lower_case=True) if ids else "",
+                      "segments_8": tok.split_segments(tokens, 8), "segments_20_q4": tok.split_segments(tokens, 20, quick_streaming_tokens=4)})
+    meta = {"vocab_size": tok.vocab_size, "unk_token_id": tok.unk_token_id, "batch_encode": tok.batch_encode(texts[:3]),
+            "vocab_head": [tok.convert_ids_to_tokens(i) for i in range(12)]}
+    with open(os.path.join(HERE, "tokenizer.json"), "w", encoding="utf-8") as f:
+        json.dump({"cases": cases, "meta": meta}, f, ensure_ascii=False, indent=1)
+    print("tokenizer.json", len(cases), "cases; vocab", tok.vocab_size)
+
+
+def tokenize_up(line):
+    from indextts.utils.common import tokenize_by_CJK_char
+    return tokenize_by_CJK_char(line)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     torch.manual_seed(0)
@@ -841,3 +881,6 @@ if __name__ == "__main__":
         make_melspec()
     if which in ("campplus", "all"):
         make_campplus()
+    if which in ("tokenizer", "all"):
+        _install_placeholders()
+        make_tokenizer()

@@ -188,6 +188,29 @@ def test_infer_emo_vector_mixes_the_emotion_banks(device):
     assert not np.array_equal(a, c)
 
 
+def test_infer_takes_a_string_with_a_tokenizer(device):
+    """infer(text: str) (infer_v2.py:697-704): tokenize -> split_segments -> ids; equals the call with those id segments."""
+    import os
+    from indextts_amd.tokenizer import TextTokenizer
+    cfg, wg, ws, wv, tts, cond = _build(device, eos_bias=-1e4)
+    tok = TextTokenizer(os.path.join(os.path.dirname(__file__), "golden", "tiny_bpe.model"))
+    assert tok.vocab_size <= cfg.gpt.number_text_tokens
+    text = "the quick brown fox, the lazy dog. speech synthesis is fun! what's next?"
+    G = dict(do_sample=False, num_beams=1, max_mel_tokens=10, max_text_tokens_per_segment=12)
+    import warnings
+    warnings.simplefilter("ignore")
+    with pytest.raises(RuntimeError):
+        tts.infer(cond, text, None, **G)
+    tts.tokenizer = tok
+    torch.manual_seed(4)
+    _, a = tts.infer(cond, text, None, **G)
+    segs = [tok.convert_tokens_to_ids(s) for s in tok.split_segments(tok.tokenize(text), 12)]
+    assert len(segs) >= 2
+    torch.manual_seed(4)
+    _, b = tts.infer(cond, segs, None, **G)
+    assert np.array_equal(a, b)
+
+
 def test_infer_streaming_contract(device):
     """stream_return (infer_v2.py:547-555, 874-886): a generator that yields, per segment, the segment's waveform ([1, n] float32
     on the CPU, scaled and clamped) and then the inter-segment silence -- and nothing else; joined, the chunks are the
