@@ -19,4 +19,21 @@ struct AttnArgs {
 
 int flash_attn_forward(const AttnArgs& a, hipStream_t stream);
 
+// The same attention (non-causal, right-padded keys) reading q / k / v as SPLIT-BF16 PLANES of one [Mrows][*] projection output
+// (plane_index(row, col, Mrows), common.h: what the LDS-DMA GEMM's epilogue writes): K / V tiles travel HBM -> LDS by
+// global_load_lds through a 3-slot ring, two tiles ahead of the MFMAs, with no register staging and no in-loop splitting.
+struct AttnPlanesArgs {
+  const void* planes = nullptr;   // hi plane; the lo plane follows at + plane_elems(Mrows, ncols)
+  int Mrows = 0, ncols = 0;       // rows / columns of the projection output (B * T, 3 * H * 64)
+  int q_col = 0, k_col = 0, v_col = 0;   // first column of q / k / v; head h at + 64 h
+  int T = 0;                      // rows (= keys) per batch row
+  int q_row0 = 0, Sq = 0;         // queries of batch row b: rows b * T + q_row0 + [0, Sq)
+  int B = 0, H = 0;
+  const int* kend = nullptr;      // [B] valid keys (<= T) or null
+  float scale = 0.125f;
+  float* o = nullptr; long o_bs = 0; int o_ts = 0;      // fp32 output rows (batch stride, token stride), or null
+  void* o_planes = nullptr;       // and / or planes over rows b * Sq + q, columns head * 64 + d
+};
+int flash_attn_planes_forward(const AttnPlanesArgs& a, hipStream_t stream);
+
 }  // namespace idxtts

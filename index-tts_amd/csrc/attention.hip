@@ -17,10 +17,22 @@
 // accumulator registers and feed the second product directly as its B operand
 //   O^T += V^T . P^T   (2 tiles of 32 d x 32 queries, k-order = accumulator row order)
 // so P never touches LDS.  Q fragments live in registers for the whole kernel (pre-scaled by 1/8).
+#include <algorithm>
+
 #include "attention.h"
 #include "prof.h"
 
 namespace idxtts {
+
+// lane <-> lane ^ 32 exchange by v_permlane32_swap (VALU) instead of ds_bpermute (an LDS round trip on the softmax's critical path)
+__device__ __forceinline__ float xor32_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 constexpr int KROW = 68;     // K tile row stride (floats): 64 + 4 pad -> conflict-free ds_read_b128 fragments
 constexpr float NEG_BIG = -1e30f;
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(256) void flash_attn_f32_kernel(const AttnArgs p) {
         s[r] = ok ? s[r] : NEG_BIG;
         mx = fmaxf(mx, s[r]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = xor32_max(mx);
       const float m_new = fmaxf(m_run, mx);
       const float alpha = expf(m_run - m_new);       // m_run = NEG_BIG -> 0 (or 1 if still nothing seen: o,l are 0 anyway)
       float psum = 0.0f;
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(256) void flash_attn_f32_kernel(const AttnArgs p) {
   }
 
   // ---- normalise and store: O^T tiles (rows = d, cols = query) -> O[b][q][head*64 + d] through LDS ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float l_tot = xor32_sum(l_run);
   const float inv_l = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
   float* stage = smem + wave * (32 * 65);            // reuse the (now idle) K/V tiles as the transpose buffer
   static_assert(4 * 32 * 65 <= 2 * 32 * KROW + 2 * 32 * 64, "output staging must fit in the K/V tiles");
@@ -317,7 +329,7 @@ __global__ __launch_bounds__(256) void flash_attn_bf16x3_kernel(const AttnArgs p
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = xor32_max(mx);
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       float psum = 0.0f;
@@ -372,7 +384,7 @@ __global__ __launch_bounds__(256) void flash_attn_bf16x3_kernel(const AttnArgs p
     __syncthreads();
   }
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float l_tot = xor32_sum(l_run);
   const float inv_l = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
   float* stage = reinterpret_cast<float*>(smem) + wave * (32 * 65);
   static_assert(4 * 32 * 65 * 4 <= 2 * ABUF, "output staging must fit in the K/V tiles");
@@ -401,6 +413,218 @@ __global__ __launch_bounds__(256) void flash_attn_bf16x3_kernel(const AttnArgs p
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Planes variant (DiT attention of s2mel): q / k / v arrive as the split-bf16 planes the qkv GEMM's epilogue wrote (rotary
+// embedding already applied), chunk-major [col / 16][row][16]: a 32-key x 16-dim block of one plane is 1 KiB of contiguous
+// memory = ONE global_load_lds_dwordx4 wave-instruction.  A K/V tile (32 keys x 64 dims x {K,V} x {hi,lo}) is 16 such pieces,
+// four per wave; tiles sit in a 3-slot LDS ring and are requested two tiles ahead of the MFMAs that consume them, so the
+// HBM / L2 latency of a tile is covered by two tiles of arithmetic (measured before: with every MFMA, split and exp removed the
+// register-staged kernel still took 58 % of its time -- one tile of load latency per iteration).
+//   LDS image of a piece: row L (32 bytes: 16 dims) holds key (L ^ 4 (c & 1)) of chunk c, its two 16-byte halves swapped when
+//   L & 8 (the swizzle of gemm_bf16x3_v2.hip): ds_read_b128 K fragments and ds_read_b64_tr_b16 V fragments are conflict-free.
+// The softmax scale rides in the exponent argument (fma), so q needs no scaling (its hi / lo planes are used as they are).
+#define ATT_GLDS16(gptr, lptr) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+constexpr int ATT_SLOT = 16 * 1024;       // 16 pieces of 1 KiB: [K hi, K lo, V hi, V lo] x 4 chunks
+constexpr int ATT_NSLOT = 3;
+
+__global__ __launch_bounds__(256) void flash_attn_planes_kernel(const AttnPlanesArgs p) {
+  __shared__ __attribute__((aligned(1024))) char smem[ATT_NSLOT * ATT_SLOT];
+
+  const int qblk = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int h = lane >> 5, j = lane & 31;
+  const int q0 = qblk * 128 + wave * 32;
+  const int qi = q0 + j;
+  const int kend = p.kend ? min(p.kend[b], p.T) : p.T;
+  const int ntiles = (kend + 31) >> 5;
+  const __bf16* const hi = static_cast<const __bf16*>(p.planes);
+  const __bf16* const lo = hi + plane_elems(p.Mrows, p.ncols);
+  const size_t rows16 = (size_t)p.Mrows * 16;
+
+  // Q^T fragments (B operand): lane (query j, half h) holds Q[qi][16c + 8h + e], e = 0..7
+  bf16x8 qh[4], ql[4];
+  {
+    const size_t qrow = (size_t)b * p.T + p.q_row0 + min(qi, p.Sq - 1);
+    const size_t base = (size_t)((p.q_col >> 4) + hd * 4) * rows16 + qrow * 16 + 8 * h;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      qh[c] = *reinterpret_cast<const bf16x8*>(hi + base + c * rows16);
+      ql[c] = *reinterpret_cast<const bf16x8*>(lo + base + c * rows16);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on only the tile DMAs are in flight: counted waits below
+
+  // DMA role: wave 0 K hi, 1 K lo, 2 V hi, 3 V lo; lane = (LDS row lrow, LDS half unit) of each of the wave's four chunk pieces
+  const int lrow = lane >> 1;
+  const int src_half = (lane & 1) ^ ((lrow >> 3) & 1);
+  const __bf16* const plane = (wave & 1) ? lo : hi;
+  const size_t cbase = (size_t)(((wave < 2 ? p.k_col : p.v_col) >> 4) + hd * 4) * rows16 + src_half * 8;
+  const size_t row_b = (size_t)b * p.T;
+  auto issue_tile = [&](int tile) {
+    char* dst = smem + (tile % ATT_NSLOT) * ATT_SLOT + wave * 4096;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int key = tile * 32 + (lrow ^ (4 * (c & 1)));
+      const size_t grow = min(row_b + key, (size_t)p.Mrows - 1);      // keys past the row's end: finite rows of a neighbour, masked below
+      ATT_GLDS16(plane + cbase + c * rows16 + grow * 16, dst + c * 1024);
+    }
+  };
+
+  f32x16 o[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
+  float m_run = NEG_BIG, l_run = 0.0f;
+  const float sc = p.scale * 1.4426950408889634f;
+
+  // fragment read offsets inside a slot
+  const int kL0 = j, kL1 = j ^ 4;
+  const int k_off0 = kL0 * 32 + ((h ^ ((kL0 >> 3) & 1)) << 4);      // even chunks
+  const int k_off1 = kL1 * 32 + ((h ^ ((kL1 >> 3) & 1)) << 4);      // odd chunks
+  const int g1 = (lane >> 4) & 1, vq = (lane & 15) >> 2, vp = lane & 3;
+  // transposing V read: lane (key 4h + vq of the 8-key group, columns 4 vp.. of chunk 2t + g1); +8 keys flips the swizzle
+  const int vL = (4 * h + vq) ^ (4 * g1);
+  const int v_off_a = 2 * 4096 + g1 * 1024 + vL * 32 + ((vp >> 1) << 4) + ((vp & 1) << 3);            // keys 16 t2 + [0, 8): L & 8 == 0
+  const int v_off_b = 2 * 4096 + g1 * 1024 + (vL + 8) * 32 + (((vp >> 1) ^ 1) << 4) + ((vp & 1) << 3);   // keys 16 t2 + [8, 16)
+
+  if (ntiles > 0) issue_tile(0);
+  if (ntiles > 1) issue_tile(1);
+  for (int tile = 0; tile < ntiles; ++tile) {
+    // tile `tile` has landed: this wave's four pieces by the counted wait (a younger tile may stay in flight), everyone's by the
+    // barrier -- which also says every wave is done reading the slot of tile - 1, the one tile + 2 is about to overwrite
+    if (tile + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (tile + 2 < ntiles) issue_tile(tile + 2);
+    const char* tb = smem + (tile % ATT_NSLOT) * ATT_SLOT;
+    const int key0 = tile * 32;
+    if (q0 < p.Sq) {      // wave-uniform
+      // ---- S^T = K . Q^T ----
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ko = (c & 1) ? k_off1 : k_off0;
+        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(tb + c * 1024 + ko);
+        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(tb + 4096 + c * 1024 + ko);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[c], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[c], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[c], s, 0, 0, 0);
+      }
+      // ---- mask (last tile only) + online softmax in the log2 domain, scale folded into the exponent ----
+      if (key0 + 32 > kend) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          s[r] = key < kend ? s[r] : NEG_BIG;
+        }
+      }
+      float mx = NEG_BIG;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = xor32_max(mx);
+      const float m_new = fmaxf(m_run, mx * sc);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float psum = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m_new));      // masked: s = -1e30 -> 0
+        s[r] = pv;
+        psum += pv;
+      }
+      l_run = l_run * alpha + psum;
+      if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      }
+      m_run = m_new;
+      bf16x8 ph[2], pl[2];
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const f32x4 a = {s[8 * t2 + 0], s[8 * t2 + 1], s[8 * t2 + 2], s[8 * t2 + 3]};
+        const f32x4 c = {s[8 * t2 + 4], s[8 * t2 + 5], s[8 * t2 + 6], s[8 * t2 + 7]};
+        bf16x4 ah, al, ch, cl;
+        split4(a, ah, al);
+        split4(c, ch, cl);
+        ph[t2] = __builtin_shufflevector(ah, ch, 0, 1, 2, 3, 4, 5, 6, 7);
+        pl[t2] = __builtin_shufflevector(al, cl, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+      // ---- O^T += V^T . P^T ----
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const char* va = tb + 16 * t2 * 32 + t * 2048;
+          typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+          const bf16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(va + v_off_a));
+          const bf16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(va + v_off_b));
+          const bf16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(va + 4096 + v_off_a));
+          const bf16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(va + 4096 + v_off_b));
+          const bf16x8 vh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+          const bf16x8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[t2], o[t], 0, 0, 0);
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[t2], o[t], 0, 0, 0);
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[t2], o[t], 0, 0, 0);
+        }
+    }
+  }
+
+  const float l_tot = xor32_sum(l_run);
+  const float inv_l = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                            // every wave is done with the ring: reuse it as the transpose buffer
+  float* stage = reinterpret_cast<float*>(smem) + wave * (32 * 65);
+  static_assert(4 * 32 * 65 * 4 <= ATT_NSLOT * ATT_SLOT, "output staging must fit in the ring");
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dd = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      stage[j * 65 + dd] = o[t][r] * inv_l;
+    }
+  __syncthreads();
+  float* ob = p.o ? p.o + (size_t)b * p.o_bs + hd * 64 : nullptr;
+  __bf16* const o_hi = static_cast<__bf16*>(p.o_planes);
+  __bf16* const o_lo = o_hi ? o_hi + plane_elems(p.B * p.Sq, p.H * 64) : nullptr;
+#pragma unroll
+  for (int it = 0; it < 32; ++it) {
+    const int qq = q0 + it;
+    if (qq < p.Sq) {
+      const float val = stage[it * 65 + lane];
+      if (ob) ob[(size_t)qq * p.o_ts + lane] = val;
+      if (o_hi) {
+        const __bf16 vhi = (__bf16)val;
+        const size_t oo = plane_index(b * p.Sq + qq, hd * 64 + lane, p.B * p.Sq);
+        o_hi[oo] = vhi;
+        o_lo[oo] = (__bf16)(val - (float)vhi);
+      }
+    }
+  }
+}
+
+int flash_attn_planes_forward(const AttnPlanesArgs& a, hipStream_t stream) {
+  if (a.B == 0 || a.H == 0 || a.Sq == 0) return 0;
+  IDX_CHECK(a.planes && (a.o || a.o_planes), "null pointer");
+  IDX_CHECK(a.Mrows > 0 && a.T > 0 && (long long)a.B * a.T <= a.Mrows && a.q_row0 >= 0 && a.q_row0 + a.Sq <= a.T, "rows");
+  IDX_CHECK((a.ncols & 15) == 0 && (a.q_col & 15) == 0 && (a.k_col & 15) == 0 && (a.v_col & 15) == 0, "columns must be multiples of 16");
+  IDX_CHECK(std::max(a.q_col, std::max(a.k_col, a.v_col)) + a.H * 64 <= a.ncols, "columns out of range");
+  IDX_CHECK((reinterpret_cast<uintptr_t>(a.planes) & 15) == 0, "planes must be 16-byte aligned");
+  dim3 grid(cdiv(a.Sq, 128), a.H, a.B);
+  const double flops = 4.0 * a.B * a.H * (double)a.Sq * a.T * 64;
+  const double bytes = 4.0 * a.B * a.H * 64.0 * (2.0 * a.Sq + 2.0 * a.T);
+  ProfScope prof(PROF_FLASH_ATTN, stream, flops, bytes);
+  hipLaunchKernelGGL(flash_attn_planes_kernel, grid, dim3(256), 0, stream, a);
+  IDX_LAUNCH_CHECK();
+  return 0;
 }
 
 int flash_attn_forward(const AttnArgs& a, hipStream_t stream) {

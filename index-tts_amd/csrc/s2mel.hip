@@ -402,14 +402,22 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
       h = dst;
     }
     if (ada(h, B.attn_g, 2 * i)) return 1;
+    bool qkv_planes = false;
     {     // qkv projection; the rotary embedding of q and k rides in its epilogue when the LDS-DMA kernel runs it
       GemmArgs g;
       g.x = chain ? nullptr : w.hn; g.x_planes = hn_p; g.ldx = D; g.y = w.qkv; g.ldy = 3 * D; g.M = M;
       const bool fuse_rope = gemm_uses_planes(B.wqkv, g);
+      // LDS-DMA GEMM: rotary embedding in its epilogue, and q / k / v leave it as split-bf16 planes (the same bytes as the fp32
+      // rows they replace) for the planes attention kernel
+      qkv_planes = fuse_rope && D == 64 * c.num_heads;
       if (fuse_rope) { g.rope = m.rope; g.rope_T = T; g.rope_cols = 2 * D; }
+      if (qkv_planes) { g.y = nullptr; g.y_planes = w.qkv; }
       if (gemm_forward(B.wqkv, g, st)) return 1;
       if (!fuse_rope && rotary_qk(w.qkv, M, c.num_heads, T, m.rope, st)) return 1;
     }
+    AttnPlanesArgs ap;
+    ap.planes = w.qkv; ap.Mrows = M; ap.ncols = 3 * D; ap.q_col = 0; ap.k_col = D; ap.v_col = 2 * D; ap.T = T; ap.q_row0 = 0; ap.Sq = T;
+    ap.B = N2; ap.H = c.num_heads; ap.kend = w.lens2; ap.scale = 0.125f; ap.o = w.att; ap.o_bs = (long)T * D; ap.o_ts = D;
     AttnArgs a;
     a.q = w.qkv; a.k = w.qkv + D; a.v = w.qkv + 2 * D; a.o = w.att;
     a.q_bs = a.k_bs = a.v_bs = (long)T * 3 * D; a.o_bs = (long)T * D;
@@ -420,8 +428,9 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
       // last block: its keys / values cover every frame, but only the tail frames' queries, attention output, projection and
       // feed-forward are ever used (nothing attends to this block's output): Mt rows instead of M from here on
       a.q = w.qkv + (size_t)t0 * 3 * D; a.Sq = Tt; a.o_bs = (long)Tt * D;
-      if (chain_t) { a.o = nullptr; a.o_planes = w.att_p; }
-      if (flash_attn_forward(a, st)) return 1;
+      ap.q_row0 = t0; ap.Sq = Tt; ap.o_bs = (long)Tt * D;
+      if (chain_t) { a.o = nullptr; a.o_planes = w.att_p; ap.o = nullptr; ap.o_planes = w.att_p; }
+      if (qkv_planes ? flash_attn_planes_forward(ap, st) : flash_attn_forward(a, st)) return 1;
       if (gather_tail_rows(w.xres, D, h, D, D, N2, T, t0, st)) return 1;                       // residual rows (xres is free here)
       if (gemm(B.wo, w.att, D, w.hmid, D, Mt, st, ACT_NONE, w.xres, D, chain_t ? w.att_p : nullptr)) return 1;
       if (ada_rows(w.hmid, B.ffn_g, 2 * i + 1, Mt, chain_t)) return 1;
@@ -432,8 +441,8 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
       h_compact = true;
       break;
     }
-    if (chain) { a.o = nullptr; a.o_planes = w.att_p; }
-    if (flash_attn_forward(a, st)) return 1;
+    if (chain) { a.o = nullptr; a.o_planes = w.att_p; ap.o = nullptr; ap.o_planes = w.att_p; }
+    if (qkv_planes ? flash_attn_planes_forward(ap, st) : flash_attn_forward(a, st)) return 1;
     if (gemm(B.wo, w.att, D, w.hmid, D, M, st, ACT_NONE, h, D, chain ? w.att_p : nullptr)) return 1;           // h + attention(...)
     if (ada(w.hmid, B.ffn_g, 2 * i + 1)) return 1;
     if (gemm(B.w13, w.hn, D, chain ? nullptr : w.ff, m.ffn, M, st, ACT_SWIGLU, nullptr, 0, hn_p, chain ? w.ff_p : nullptr)) return 1;
