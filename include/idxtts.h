@@ -160,6 +160,10 @@ int idxtts_gpt_create(const idxtts_gpt_config* cfg, idxtts_ctx** out);
  * (mathematically the same network up to Q) -- and prefill, latent pass and decode are all packed from them, so the three
  * passes run one model and idxtts_ctx_get_tensor returns exactly that model for the reference / oracle to run. */
 int idxtts_gpt_quantize_weights(idxtts_ctx* ctx, int format);
+/* Greedy generations keep their instantiated decode-step hipGraph per (workspace address and size, B, prompt length, max_new_tokens,
+ * penalty): the same shapes on the same workspace replay it without re-capturing (at most 8 are kept, least recently used first
+ * out).  Returns how many are held (diagnostics / tests), -1 for a non-GPT context. */
+int idxtts_gpt_graph_cache_entries(idxtts_ctx* ctx);
 size_t idxtts_gpt_workspace_bytes(const idxtts_ctx* ctx, int B, int S, int max_new_tokens);
 /* out[r] = text_emb[text_ids[r]] + text_pos[text_pos_idx[r]] + mel_emb[mel_ids[r]] + mel_pos[mel_pos_idx[r]] + extra[extra_idx[r]],
  * every term skipped where its index is < 0 (or its index array is NULL).  Index arrays are device int32 [rows].

@@ -328,6 +328,14 @@ int idxtts_gpt_quantize_weights(idxtts_ctx* ctx, int format) {
   API_END
 }
 
+int idxtts_gpt_graph_cache_entries(idxtts_ctx* ctx) {
+  if (!ctx || !ctx->finalized) return -1;
+  auto* m = dynamic_cast<GPTModel*>(ctx->model.get());
+  if (!m) return -1;
+  std::lock_guard<std::mutex> l(m->graph_mu);
+  return (int)m->graph_cache.size();
+}
+
 size_t idxtts_gpt_workspace_bytes(const idxtts_ctx* ctx, int B, int S, int max_new_tokens) {
   if (!ctx || B <= 0 || S <= 0 || max_new_tokens < 0 || !ctx->finalized) return 0;
   auto* m = dynamic_cast<const GPTModel*>(ctx->model.get());

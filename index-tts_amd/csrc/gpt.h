@@ -1,4 +1,7 @@
 #pragma once
+#include <mutex>
+#include <vector>
+
 #include "../../include/idxtts.h"
 #include "attention.h"
 #include "beam.h"
@@ -29,7 +32,10 @@ struct GPTModel : ModelBase {
   int weight_fmt = WFMT_F32;      // storage format of the decode weight streams (quantize_weights)
   hipStream_t own_stream = nullptr;
   int* oob_flag = nullptr;        // device int: set by the embedding gather when an index exceeds its table
-  ~GPTModel() override { if (own_stream) (void)hipStreamDestroy(own_stream); }
+  ~GPTModel() override {
+    for (GraphSlot& g : graph_cache) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+  }
 
   struct Buffers {
     float *x, *h, *qkv, *att, *ff;            // [B*S][..] prefill / latent activations
@@ -41,8 +47,19 @@ struct GPTModel : ModelBase {
     float* attn_part; unsigned* attn_cnt;     // key-split decode attention: [B][H][<=16][66] partials, [B][H] counters
     unsigned* ksb_cnt;                        // [d/16] arrival counters of the fused K-split mlp.c_proj (zeroed per generate)
     DecodeState* state;
+    long long* codes;                         // [B][max_new] generated codes of the call in flight (copied to the caller's tensor at the end)
     size_t bytes;
   };
+  // Instantiated decode-step graphs of greedy generations, keyed by everything the captured launches depend on (workspace
+  // address and carve, batch, penalty): a server replaying the same shapes on the same stream re-captures nothing.
+  struct GraphSlot {
+    void* ws = nullptr; size_t ws_bytes = 0; int B = 0, S = 0, max_new = 0; float penalty = 0.0f;
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; unsigned long stamp = 0; bool in_use = false;
+  };
+  std::vector<GraphSlot> graph_cache;
+  std::mutex graph_mu;
+  unsigned long graph_stamp = 0;
+  static constexpr size_t GRAPH_CACHE_MAX = 8;
 
   explicit GPTModel(const idxtts_gpt_config& c);
   bool accepts(const std::string& name) const override;

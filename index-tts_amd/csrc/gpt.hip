@@ -251,6 +251,7 @@ GPTModel::Buffers GPTModel::carve(void* ws, int B, int S, int max_new) const {
   b.attn_cnt = c.take<unsigned>((size_t)B * cfg.heads);
   b.attn_part = c.take<float>((size_t)B * cfg.heads * 16 * 66);
   b.state = c.take<DecodeState>(1);
+  b.codes = c.take<long long>((size_t)B * (max_new > 0 ? max_new : 0));
   b.bytes = (c.off + 255) & ~(size_t)255;
   return b;
 }
@@ -390,6 +391,9 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
   IDX_CHECK(max_new + 1 < cfg.mel_pos_len, "max_new_tokens exceeds the mel position table");
   IDX_CHECK(ws && ws_bytes >= workspace_bytes(B, S, max_new), "workspace too small");
   Buffers w = carve(ws, B, S, max_new);
+  long long* const user_codes = codes;
+  codes = w.codes;           // every launch writes here (a stable address: the captured decode step can be kept); copied out at the end
+  IDX_HIP(hipMemcpyAsync(codes, user_codes, (size_t)B * max_new * sizeof(long long), hipMemcpyDeviceToDevice, st));      // the caller's pad fill
 
   // ---- per-call state ----
   std::vector<int> kstart(B, 0);
@@ -433,24 +437,61 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
   }
 
   // ---- decode ----
-  struct GraphGuard {      // released on every return path (error paths after the capture included)
+  struct GraphGuard {      // a graph that is not kept: released on every return path (error paths after the capture included)
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     ~GraphGuard() { if (exec) (void)hipGraphExecDestroy(exec); if (graph) (void)hipGraphDestroy(graph); }
   } gg;
-  hipGraph_t& graph = gg.graph;
-  hipGraphExec_t& exec = gg.exec;
+  struct SlotLease {       // a cached graph in use by this call
+    GPTModel* m = nullptr; int idx = -1;
+    ~SlotLease() { if (m && idx >= 0) { std::lock_guard<std::mutex> l(m->graph_mu); m->graph_cache[idx].in_use = false; } }
+  } lease;
+  hipGraphExec_t exec = nullptr;
   const bool graph_ok = use_graph && !logits_out && !prof_enabled();
+  const bool cacheable = samp.mode == 0 && !tl_beam;      // greedy: nothing call-specific is baked into the launches
   int n_first = 1;
   if (graph_ok && max_new > 2) {
     // step 1 runs eagerly (first-use function attributes are set outside the capture), steps >= 2 replay
     if (decode_step(w, B, penalty, codes, max_new, nullptr, st)) return 1;
     n_first = 2;
-    IDX_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    const int rc = decode_step(w, B, penalty, codes, max_new, nullptr, st);
-    hipError_t e = hipStreamEndCapture(st, &graph);
-    if (rc) return 1;
-    IDX_HIP(e);
-    IDX_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    if (cacheable) {
+      std::lock_guard<std::mutex> l(graph_mu);
+      for (size_t i = 0; i < graph_cache.size(); ++i) {
+        GraphSlot& g = graph_cache[i];
+        if (!g.in_use && g.ws == ws && g.ws_bytes == ws_bytes && g.B == B && g.S == S && g.max_new == max_new && g.penalty == penalty) {
+          g.in_use = true; g.stamp = ++graph_stamp; exec = g.exec; lease.m = this; lease.idx = (int)i;
+          break;
+        }
+      }
+    }
+    if (!exec) {
+      IDX_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      const int rc = decode_step(w, B, penalty, codes, max_new, nullptr, st);
+      hipError_t e = hipStreamEndCapture(st, &gg.graph);
+      if (rc) return 1;
+      IDX_HIP(e);
+      IDX_HIP(hipGraphInstantiate(&gg.exec, gg.graph, nullptr, nullptr, 0));
+      exec = gg.exec;
+      if (cacheable) {      // keep it: hand the objects over to a cache slot (a free one, or the least recently used idle one)
+        std::lock_guard<std::mutex> l(graph_mu);
+        int slot = -1;
+        // an idle entry on the same workspace address describes launches that can no longer be replayed safely: replace it
+        for (size_t i = 0; i < graph_cache.size() && slot < 0; ++i) if (!graph_cache[i].in_use && graph_cache[i].ws == ws) slot = (int)i;
+        if (slot < 0 && graph_cache.size() < GRAPH_CACHE_MAX) { graph_cache.emplace_back(); slot = (int)graph_cache.size() - 1; }
+        if (slot < 0) {
+          for (size_t i = 0; i < graph_cache.size(); ++i)
+            if (!graph_cache[i].in_use && (slot < 0 || graph_cache[i].stamp < graph_cache[slot].stamp)) slot = (int)i;
+        }
+        if (slot >= 0) {
+          GraphSlot& g = graph_cache[slot];
+          if (g.exec) (void)hipGraphExecDestroy(g.exec);
+          if (g.graph) (void)hipGraphDestroy(g.graph);
+          g.ws = ws; g.ws_bytes = ws_bytes; g.B = B; g.S = S; g.max_new = max_new; g.penalty = penalty;
+          g.graph = gg.graph; g.exec = gg.exec; g.stamp = ++graph_stamp; g.in_use = true;
+          gg.graph = nullptr; gg.exec = nullptr;
+          lease.m = this; lease.idx = slot;
+        }
+      }
+    }
   }
   std::vector<int> fin(B);
   int steps_done = n_first;
@@ -472,6 +513,7 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
   }
   // exact HF length: generation stops at the first step after which every row has emitted the stop token
   std::vector<long long> hc((size_t)B * max_new);
+  IDX_HIP(hipMemcpyAsync(user_codes, codes, hc.size() * sizeof(long long), hipMemcpyDeviceToDevice, st));
   IDX_HIP(hipMemcpyAsync(hc.data(), codes, hc.size() * sizeof(long long), hipMemcpyDeviceToHost, st));
   IDX_HIP(hipStreamSynchronize(st));
   int n_steps = steps_done;

@@ -26,7 +26,7 @@ SYMBOLS = [
     "idxtts_s2mel_create", "idxtts_s2mel_cond_workspace_bytes", "idxtts_s2mel_prepare_cond",
     "idxtts_s2mel_cfm_workspace_bytes", "idxtts_s2mel_cfm", "idxtts_set_gemm_mode", "idxtts_get_gemm_mode",
     "idxtts_s2mel_estimator", "idxtts_s2mel_regulate", "idxtts_cond_create", "idxtts_cond_workspace_bytes", "idxtts_cond_forward", "idxtts_emovec_merge",
-    "idxtts_w2vbert_create", "idxtts_w2vbert_workspace_bytes", "idxtts_w2vbert_forward",
+    "idxtts_gpt_graph_cache_entries", "idxtts_w2vbert_create", "idxtts_w2vbert_workspace_bytes", "idxtts_w2vbert_forward",
     "idxtts_repcodec_create", "idxtts_repcodec_workspace_bytes", "idxtts_repcodec_quantize",
     "idxtts_melspec_create", "idxtts_melspec_frames", "idxtts_melspec_workspace_bytes", "idxtts_melspec_forward",
     "idxtts_campplus_create", "idxtts_campplus_workspace_bytes", "idxtts_campplus_forward",
@@ -177,6 +177,7 @@ def load() -> ctypes.CDLL:
     lib.idxtts_repcodec_workspace_bytes.argtypes = [c_void_p, c_int, c_int]
     lib.idxtts_repcodec_workspace_bytes.restype = c_size_t
     lib.idxtts_repcodec_quantize.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.idxtts_gpt_graph_cache_entries.argtypes = [c_void_p]
     lib.idxtts_w2vbert_create.argtypes = [POINTER(W2VBertConfigC), POINTER(c_void_p)]
     lib.idxtts_w2vbert_workspace_bytes.argtypes = [c_void_p, c_int, c_int]
     lib.idxtts_w2vbert_workspace_bytes.restype = c_size_t

@@ -186,6 +186,41 @@ def test_latent_pass_vs_golden(device, golden_dir):
     np.testing.assert_allclose(out.cpu().numpy(), g["latent"], rtol=0, atol=5e-5)
 
 
+def test_decode_graph_is_kept_per_shape_and_replayed(device, golden_dir):
+    """Greedy generations keep their instantiated decode-step graph per (workspace, batch, prompt length, max_new_tokens, penalty):
+    the same call again re-captures nothing and returns the same codes; other shapes, an interleaved sampled call and a second
+    stream each get their own; all equal the eager launches."""
+    g, cfg, w, uv = _tiny(golden_dir, device)
+    lib = _lib.load()
+    B, L = g["greedy_text"].shape
+    NEW = g["greedy_codes"].shape[1]
+    conds = torch.from_numpy(synth.uniform("golden/gpt/conds", (B, cfg.cond_latents + 2, cfg.model_dim), 0.5)).to(device)
+    text = torch.from_numpy(g["greedy_text"])
+    fake, emb, mask = uv.prepare_gpt_inputs(conds, text)
+    kw = dict(stop_tokens=[cfg.stop_mel_token], attention_mask=mask, tts_embeddings=emb, repetition_penalty=10.0)
+    run = lambda n=NEW, **k: uv.generate(fake, max_new_tokens=n, **{**kw, **k})[:, fake.shape[1]:].cpu().numpy()
+    assert lib.idxtts_gpt_graph_cache_entries(uv._h) == 0
+    a = run()
+    assert lib.idxtts_gpt_graph_cache_entries(uv._h) == 1 and np.array_equal(a, g["greedy_codes"])
+    assert np.array_equal(run(), a) and lib.idxtts_gpt_graph_cache_entries(uv._h) == 1          # replayed, not re-captured
+    shorter = run(NEW - 3)                                                                        # another shape on the same workspace
+    assert np.array_equal(shorter, run(NEW - 3, use_graph=False))
+    n_after = lib.idxtts_gpt_graph_cache_entries(uv._h)
+    assert n_after in (1, 2)                      # same workspace address -> the entry is replaced; a regrown workspace -> a second one
+    sampled = run(do_sample=True, top_k=5, temperature=0.9, generator=torch.Generator().manual_seed(3))     # sampling: never cached
+    assert sampled.shape[0] == B and lib.idxtts_gpt_graph_cache_entries(uv._h) == n_after
+    assert np.array_equal(run(), a) and np.array_equal(run(repetition_penalty=2.0), run(repetition_penalty=2.0, use_graph=False))
+    s2 = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(s2):                                                                   # its own workspace, its own graph
+        b = run()
+        s2.synchronize()
+    assert np.array_equal(b, a)
+    for _ in range(12):                                                                            # the cache is bounded
+        run(NEW - 1 - (_ % 5))
+    assert lib.idxtts_gpt_graph_cache_entries(uv._h) <= 8
+    assert np.array_equal(run(), a)
+
+
 def test_eos_and_padding_invariance(device):
     """Rows that stop keep emitting the stop token; a row decoded alone equals the same row left-padded in a batch
     (the reference's own property test, tests/padding_test.py:35-89); results equal the CPU oracle token for token."""
