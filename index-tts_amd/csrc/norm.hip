@@ -162,45 +162,64 @@ __global__ __launch_bounds__(256) void rows_norm_kernel(const RowsNormArgs p) {
   for (int i = 0; i < nper; ++i) { const int e = tid + (i << 8); if (e < d) put(e, v[i]); }
 }
 
-// adaLN-RMSNorm of the DiT (d = 512) straight to split-bf16 planes: one 128-lane half-workgroup per row, 16-byte loads,
-// 8-byte plane stores (the four lanes of a 16-k chunk write 32 contiguous bytes; rows of a workgroup are adjacent).
+// adaLN-RMSNorm of the DiT (d = 512) straight to split-bf16 planes.  One wave per row (a lane owns 8 consecutive columns: 32-byte
+// loads, the row's 2 KiB contiguous; sum of squares by an xor butterfly, no workgroup barrier in the reduction), 16 rows per
+// workgroup with all their loads in flight together; the hi / lo images of the 16 rows are staged in LDS chunk-major
+// ([32 chunks][16 rows][16 columns] per plane) so that every global store instruction writes whole 512-byte runs of the plane layout
+// (plane_index: the 16 rows of a 16-column chunk are adjacent) instead of 32-byte pieces.
 // Same arithmetic as the generic kernel's NORM_ADA_RMS branch (sum of squares in a different order).
-constexpr int ADA_RPW = 4;      // row pairs per workgroup: the next pair's row is in flight while the current one is normalised
+constexpr int ADA_ROWS = 16;
 __global__ __launch_bounds__(256) void ada_rms_planes512_kernel(const RowsNormArgs p) {
-  __shared__ float red[2][4];
-  const int tid = threadIdx.x, half = tid >> 7, t = tid & 127;
-  const f32x4 g = *reinterpret_cast<const f32x4*>(p.g1 + 4 * t);
-  __bf16* y_hi = static_cast<__bf16*>(p.y_planes);
-  auto load_row = [&](int m) {
-    return m < p.M ? *reinterpret_cast<const f32x4*>(p.x_in + (size_t)m * p.ld_in + 4 * t) : f32x4{0.f, 0.f, 0.f, 0.f};
-  };
-  const int m0 = blockIdx.x * 2 * ADA_RPW + half;
-  f32x4 xn = load_row(m0);
+  __shared__ __attribute__((aligned(16))) char tile[2 * 32 * ADA_ROWS * 32];      // hi plane image, lo plane image: 16 KiB each
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m0 = blockIdx.x * ADA_ROWS;
+  f32x4 xa[4], xb[4];
 #pragma unroll
-  for (int i = 0; i < ADA_RPW; ++i) {
-    const int m = m0 + 2 * i;
-    const f32x4 x = xn;
-    if (i + 1 < ADA_RPW) xn = load_row(m + 2);
-    float ss = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wave * 4 + i;
+    const float* row = p.x_in + (size_t)min(m, p.M - 1) * p.ld_in + 8 * lane;
+    xa[i] = *reinterpret_cast<const f32x4*>(row);
+    xb[i] = *reinterpret_cast<const f32x4*>(row + 4);
+  }
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(p.g1 + 8 * lane), gb = *reinterpret_cast<const f32x4*>(p.g1 + 8 * lane + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave * 4 + i, m = min(m0 + r, p.M - 1);
+    const f32x4 a = xa[i], c = xb[i];
+    float ss = a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3] + c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
-    if ((tid & 63) == 0) red[i & 1][tid >> 6] = ss;
-    __syncthreads();                  // red[] alternates, so one barrier per row pair is enough
-    const float r = rsqrtf((red[i & 1][2 * half] + red[i & 1][2 * half + 1]) * (1.0f / 512.0f) + p.eps);
-    if (m < p.M) {
-      const int b = p.rows_per_batch > 0 ? m / p.rows_per_batch : 0;
-      f32x4 o = {x[0] * r * g[0], x[1] * r * g[1], x[2] * r * g[2], x[3] * r * g[3]};
-      if (p.mod_a) {
-        const f32x4 wm = *reinterpret_cast<const f32x4*>(p.mod_a + (size_t)b * p.ld_mod + 4 * t);
-        const f32x4 bm = *reinterpret_cast<const f32x4*>(p.mod_b + (size_t)b * p.ld_mod + 4 * t);
-        o = f32x4{wm[0] * o[0] + bm[0], wm[1] * o[1] + bm[1], wm[2] * o[2] + bm[2], wm[3] * o[3] + bm[3]};
-      }
-      idx_bf16x4 hi, lo;
-      split_bf16_x4(o, hi, lo);
-      const size_t off = plane_index(m, 4 * t, p.M);
-      *reinterpret_cast<idx_bf16x4*>(y_hi + off) = hi;
-      *reinterpret_cast<idx_bf16x4*>(y_hi + plane_elems(p.M, 512) + off) = lo;
+    const float rs = rsqrtf(ss * (1.0f / 512.0f) + p.eps);
+    f32x4 oa = {a[0] * rs * ga[0], a[1] * rs * ga[1], a[2] * rs * ga[2], a[3] * rs * ga[3]};
+    f32x4 ob = {c[0] * rs * gb[0], c[1] * rs * gb[1], c[2] * rs * gb[2], c[3] * rs * gb[3]};
+    if (p.mod_a) {
+      const int bb = p.rows_per_batch > 0 ? m / p.rows_per_batch : 0;
+      const float* wm = p.mod_a + (size_t)bb * p.ld_mod + 8 * lane;
+      const float* bm = p.mod_b + (size_t)bb * p.ld_mod + 8 * lane;
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wm), w1 = *reinterpret_cast<const f32x4*>(wm + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bm), b1 = *reinterpret_cast<const f32x4*>(bm + 4);
+      oa = f32x4{w0[0] * oa[0] + b0[0], w0[1] * oa[1] + b0[1], w0[2] * oa[2] + b0[2], w0[3] * oa[3] + b0[3]};
+      ob = f32x4{w1[0] * ob[0] + b1[0], w1[1] * ob[1] + b1[1], w1[2] * ob[2] + b1[2], w1[3] * ob[3] + b1[3]};
     }
+    idx_bf16x4 h0, l0, h1, l1;
+    split_bf16_x4(oa, h0, l0);
+    split_bf16_x4(ob, h1, l1);
+    // lane = columns 8 lane .. 8 lane + 7 = half (lane & 1) of chunk (lane >> 1)
+    char* dst = tile + (lane >> 1) * (ADA_ROWS * 32) + r * 32 + (lane & 1) * 16;
+    *reinterpret_cast<bf16x8_t*>(dst) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    *reinterpret_cast<bf16x8_t*>(dst + 32 * ADA_ROWS * 32) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+  __syncthreads();
+  char* y_hi = static_cast<char*>(p.y_planes);
+  const size_t plane_bytes = plane_elems(p.M, 512) * sizeof(__bf16);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int e = q * 256 + tid;                 // 16-byte unit: [plane 2][chunk 32][unit 32]
+    const int pl = e >> 10, c = (e >> 5) & 31, u = e & 31;
+    if (m0 + (u >> 1) < p.M)
+      *reinterpret_cast<f32x4*>(y_hi + pl * plane_bytes + ((size_t)c * p.M + m0) * 32 + u * 16) =
+          *reinterpret_cast<const f32x4*>(tile + pl * (32 * ADA_ROWS * 32) + c * (ADA_ROWS * 32) + u * 16);
   }
 }
 
@@ -218,7 +237,7 @@ int rows_norm_forward(const RowsNormArgs& a, hipStream_t stream) {
   if (a.mode == NORM_ADA_RMS && a.d == 512 && a.y_planes && !a.y && a.x_in && !a.num_partials && !a.add_bias && !a.x_out && !a.in_frag &&
       a.in_rows_per_batch == 0 && (a.ld_in & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.x_in) | reinterpret_cast<uintptr_t>(a.g1) | reinterpret_cast<uintptr_t>(a.mod_a) |
                                reinterpret_cast<uintptr_t>(a.mod_b)) & 15) == 0 && (a.ld_mod & 3) == 0) {
-    hipLaunchKernelGGL(ada_rms_planes512_kernel, dim3(cdiv(a.M, 2 * ADA_RPW)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(ada_rms_planes512_kernel, dim3(cdiv(a.M, ADA_ROWS)), dim3(256), 0, stream, a);
     IDX_LAUNCH_CHECK();
     return 0;
   }
