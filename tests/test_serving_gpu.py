@@ -105,3 +105,31 @@ def test_fullsize_decode_beside_split_bf16_convolutions_is_bit_identical(device)
     finally:
         stop.set()
         th.join()
+
+
+def test_fullsize_pipeline_three_lanes_equals_sequential(device):
+    """The batch pipeline at FULL model size (where the concurrency defect of round 2 lived): three decode chains in flight beside the
+    acoustic stage, 5 batches of 4 utterances x 48 codes with different texts; every waveform equals the sequential call bit for bit."""
+    from indextts_amd.infer_v2 import IndexTTS2, PromptConditioning
+    from indextts_amd.serving import BatchPipeline
+    cfg = PipelineConfig()
+    wg = weights.synth_gpt_weights(cfg.gpt, tag="bench/gpt")
+    wg["mel_head.bias"] = wg["mel_head.bias"].copy()
+    wg["mel_head.bias"][cfg.gpt.stop_mel_token] = -1e4
+    tts = IndexTTS2.from_state_dicts(cfg, wg, weights.synth_s2mel_weights(cfg.s2mel, tag="bench/s2mel"),
+                                     weights.synth_bigvgan_weights(cfg.bigvgan, tag="bench/bigvgan"), device=device, gpt_weight_format="bf16")
+    cond = PromptConditioning.synthetic(cfg, prompt_frames=300, tag="t/serve/fullprompt").to(device)
+    nb, B, L, M = 5, 4, 40, 48
+    Tg = int(M * cfg.code_to_frame)
+    texts = [torch.from_numpy(synth.integers(f"t/serve/full/text{k}", (B, L), 2, cfg.gpt.number_text_tokens)) for k in range(nb)]
+    noises = [torch.from_numpy(synth.uniform(f"t/serve/full/noise{k}", (B, cfg.s2mel.in_channels, 300 + Tg), 1.5)).to(device) for k in range(nb)]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = [tts.synthesize_batch(t, cond, max_mel_tokens=M, noise=n) for t, n in zip(texts, noises)]
+        torch.cuda.synchronize()
+        with BatchPipeline(tts, decode_lanes=3) as pipe:
+            got = [f.result() for f in [pipe.submit(t, cond, max_mel_tokens=M, noise=n) for t, n in zip(texts, noises)]]
+    for k in range(nb):
+        for a, b in zip(got[k], want[k]):
+            assert torch.equal(a, b), k
