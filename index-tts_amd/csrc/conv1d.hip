@@ -19,6 +19,7 @@
 // the n-tiles n = x (mod 8) and walks them m-tile-major; the 32 CUs of an XCD then stream
 // the SAME weight slice through their shared 4 MiB L2 while their x tiles differ.
 #include "conv1d.h"
+#include "conv_epilogue.h"
 #include "gemm.h"
 #include "prof.h"
 
@@ -91,7 +92,7 @@ struct ConvKP {
 };
 
 template <int TM, int TN, int WGM, int WGN>
-__global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvKP p) {
+__global__ __launch_bounds__(256, (TM == 3 ? 2 : 3)) void conv1d_mfma_kernel(const ConvKP p) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   constexpr int NSUB = TM * WGM;
   constexpr int NXR = (BN + CONV_MAX_HALO + 63) / 64;   // x-tile loads per lane per row
@@ -226,34 +227,8 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvKP p) {
     tap = ntap;
   }
 
-  // ---- epilogue: bias, residual, scale, (accumulate), store ----
-  const int u_log2 = p.ups_log2, u_mask = (1 << u_log2) - 1;
-  const int Cout = p.M >> u_log2;
-  const size_t Tout = (size_t)T << u_log2;
-#pragma unroll
-  for (int mt = 0; mt < TM; ++mt) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m_blk * BM + (wm * TM + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (m >= p.M) continue;
-      const int co = m >> u_log2, ph = m & u_mask;
-      const float bias = p.bias ? p.bias[co] : 0.0f;
-      const size_t rowoff = ((size_t)b * Cout + co) * Tout + ph;
-      const size_t own_len = p.lens ? (size_t)p.lens[b] * p.len_mul_out : Tout;     // this row's valid output samples
-#pragma unroll
-      for (int nt = 0; nt < TN; ++nt) {
-        const int n = t0 + (wn * TN + nt) * 32 + j;
-        if (n >= T) continue;
-        const size_t idx = rowoff + ((size_t)n << u_log2);
-        float v = acc[mt][nt][r] + bias;
-        if (p.res) v += p.res[idx];
-        v *= p.scale;
-        if (((size_t)n << u_log2) + ph >= own_len) v = 0.0f;
-        if (p.accum) v += p.y[idx];
-        p.y[idx] = v;
-      }
-    }
-  }
+  // ---- epilogue: bias, residual, scale, (accumulate), store: operands requested in batches ahead of the stores (conv_epilogue.h) ----
+  conv_epilogue<TM, TN>(p, acc, m_blk * BM + wm * TM * 32, t0 + wn * TN * 32, b, T, h, j);
 }
 
 template <int TM, int TN, int WGM, int WGN, int CAT>

@@ -14,6 +14,7 @@
 #include <cstring>
 
 #include "conv1d.h"
+#include "conv_epilogue.h"
 #include "prof.h"
 
 namespace idxtts {
@@ -75,7 +76,7 @@ struct ConvKP16 {
 constexpr int XROW_B = 32;            // bytes per LDS x row (16 ci bf16)
 
 template <int TM, int TN, int WGM, int WGN>
-__global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(const ConvKP16 p) {
+__global__ __launch_bounds__(256, (TM == 3 ? 2 : 3)) void conv1d_bf16x3_kernel(const ConvKP16 p) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   constexpr int NSUB = TM * WGM;
   constexpr int NXJ = (BN + CONV_MAX_HALO + 63) / 64;    // time steps per lane in the x loader
@@ -218,34 +219,8 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(const ConvKP16 p) {
     tap = ntap;
   }
 
-  // ---- epilogue: bias, residual, scale, (accumulate), store (as conv1d.hip) ----
-  const int u_log2 = p.ups_log2, u_mask = (1 << u_log2) - 1;
-  const int Cout = p.M >> u_log2;
-  const size_t Tout = (size_t)T << u_log2;
-#pragma unroll
-  for (int mt = 0; mt < TM; ++mt) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m_blk * BM + (wm * TM + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (m >= p.M) continue;
-      const int co = m >> u_log2, ph = m & u_mask;
-      const float bias = p.bias ? p.bias[co] : 0.0f;
-      const size_t rowoff = ((size_t)b * Cout + co) * Tout + ph;
-      const size_t own_len = p.lens ? (size_t)p.lens[b] * p.len_mul_out : Tout;     // this row's valid output samples
-#pragma unroll
-      for (int nt = 0; nt < TN; ++nt) {
-        const int n = t0 + (wn * TN + nt) * 32 + j;
-        if (n >= T) continue;
-        const size_t idx = rowoff + ((size_t)n << u_log2);
-        float v = acc[mt][nt][r] + bias;
-        if (p.res) v += p.res[idx];
-        v *= p.scale;
-        if (((size_t)n << u_log2) + ph >= own_len) v = 0.0f;
-        if (p.accum) v += p.y[idx];
-        p.y[idx] = v;
-      }
-    }
-  }
+  // ---- epilogue: bias, residual, scale, (accumulate), store: operands requested in batches ahead of the stores (conv_epilogue.h) ----
+  conv_epilogue<TM, TN>(p, acc, m_blk * BM + wm * TM * 32, t0 + wn * TN * 32, b, T, h, j);
 }
 
 template <int TM, int TN, int WGM, int WGN, int CAT>

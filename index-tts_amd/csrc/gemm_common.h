@@ -85,16 +85,28 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmKP& p, f32x16 (&acc)[T
     const int n = col0 + nt * 32 + j;
     if (n >= p.N) continue;
     const float bias = p.bias ? p.bias[n] : 0.0f;
+    // the residual may alias the output (in-place x += ...), so the compiler keeps every load behind the store before it: request a
+    // batch of 8 residual values first, then finish and store those 8 elements (a thread reads only the elements it writes)
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = row0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= p.M) continue;
-        float v = act_apply(acc[mt][nt][r] + bias, p.act) * p.out_scale;
-        if (p.res) v += p.res[(size_t)m * p.ldr + n];
-        if (row_masked(m)) v = 0.0f;
-        p.y[(size_t)m * p.ldy + n] = v;
+      for (int half = 0; half < 2; ++half) {
+        float rv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = half * 8 + q;
+          const int m = row0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          rv[q] = (p.res && m < p.M) ? p.res[(size_t)m * p.ldr + n] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = half * 8 + q;
+          const int m = row0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m >= p.M) continue;
+          float v = act_apply(acc[mt][nt][r] + bias, p.act) * p.out_scale + rv[q];
+          if (row_masked(m)) v = 0.0f;
+          p.y[(size_t)m * p.ldy + n] = v;
+        }
       }
   }
 }
