@@ -165,7 +165,23 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmKP& p, f32x16 (&acc)
         if (paired && nb1 + e < p.N) b1[e] = p.bias[nb1 + e];
       }
     }
-    for (int rr = wave * (SLAB / NW) + sub; rr < (wave + 1) * (SLAB / NW); rr += rpi) {
+    // The residual may alias the output (in-place h += ...): a residual load placed next to its row's store stays behind the
+    // previous row's store, and its data then waits for that store's acknowledgement (vmcnt counts loads and stores in issue
+    // order) -- one HBM write round trip per row.  All residual rows of this wave and slab are requested first instead.
+    constexpr int MAXIT = SLAB / NW;
+    f32x4 rres[MAXIT];
+    const bool res_vec = p.res && vec_ok && col_ok && n_out + 3 < n_lim;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int rr = wave * (SLAB / NW) + sub + it * rpi;
+      const int m = row_base + slab * SLAB + rr;
+      rres[it] = (res_vec && rr < (wave + 1) * (SLAB / NW) && m < p.M) ? *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + n_out)
+                                                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int rr = wave * (SLAB / NW) + sub + it * rpi;
+      if (rr >= (wave + 1) * (SLAB / NW)) continue;
       const int m = row_base + slab * SLAB + rr;
       if (m >= p.M || !col_ok) continue;
       f32x4 v = *reinterpret_cast<const f32x4*>(src_off + rr * RS) + b0;
@@ -190,7 +206,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmKP& p, f32x16 (&acc)
       }
       float* dst = p.y + (size_t)m * p.ldy + n_out;
       if (vec_ok && n_out + 3 < n_lim) {
-        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + n_out);
+        if (p.res) v += rres[it];
         if (masked) v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (p.y) *reinterpret_cast<f32x4*>(dst) = v;
         if (p.y_hi) {       // n_out % 4 == 0: the four columns share a 16-k chunk
