@@ -3,7 +3,7 @@
 //
 // The residual (and the accumulate operand) may alias the output, so a load written next to its store could not be moved by the
 // compiler: the tile's epilogue used to be a chain of dependent load -> add -> store round trips (measured on the narrow vocoder
-// convolutions: 414 of 738 us per launch went to the residual reads alone, tools/conv_probe2.hip).  Here every element's operands of
+// convolutions: 414 of 738 us per launch went to the residual reads alone).  Here every element's operands of
 // a quarter of an accumulator tile (4 rows x TN tiles) are requested first and consumed afterwards: a thread still reads exactly the
 // elements it writes, before it writes them.
 #pragma once
