@@ -11,12 +11,68 @@
 
 namespace idxtts {
 
+// 4 x 4 transpose across the four lanes of a quad and four registers (two DPP exchange stages): on return a[c] holds what lane
+// (quad base + c) had in a[lane & 3].
+__device__ __forceinline__ void quad_transpose4(float (&a)[4], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+  auto xchg = [](float v, int ctrl_is_xor2) {
+    const int x = __float_as_int(v);
+    return __int_as_float(ctrl_is_xor2 ? __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, true) : __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, true));
+  };
+  float r01 = xchg(b0 ? a[0] : a[1], 0), r23 = xchg(b0 ? a[2] : a[3], 0);
+  if (b0) { a[0] = r01; a[2] = r23; } else { a[1] = r01; a[3] = r23; }
+  float r02 = xchg(b1 ? a[0] : a[2], 1), r13 = xchg(b1 ? a[1] : a[3], 1);
+  if (b1) { a[0] = r02; a[1] = r13; } else { a[2] = r02; a[3] = r13; }
+}
+
 template <int TM, int TN, typename P>
 __device__ __forceinline__ void conv_epilogue(const P& p, f32x16 (&acc)[TM][TN], int row_base, int col_base, int b, int T, int h, int j) {
   const int u_log2 = p.ups_log2, u_mask = (1 << u_log2) - 1;
   const int Cout = p.M >> u_log2;
   const size_t Tout = (size_t)T << u_log2;
   const size_t own_len = p.lens ? (size_t)p.lens[b] * p.len_mul_out : Tout;     // this row's valid output samples
+  // Wide form (plain convolutions over rows of a multiple of 4 samples, 16-byte aligned tensors): the four accumulator registers of a
+  // group are four consecutive ROWS of one column; a quad transpose turns them into four consecutive COLUMNS of one row per lane, so the
+  // residual / accumulate reads and the store are 16 bytes per lane -- a quarter of the memory instructions, eight 128-byte runs each.
+  const bool wide = u_log2 == 0 && (T & 3) == 0 && (reinterpret_cast<uintptr_t>(p.y) & 15) == 0 &&
+                    (!p.res || (reinterpret_cast<uintptr_t>(p.res) & 15) == 0);
+  if (wide) {
+    const int lane_q = j & 3, jb = j & ~3;
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+#pragma unroll
+      for (int grp = 0; grp < 4; ++grp) {
+        const int m = row_base + mt * 32 + lane_q + 8 * grp + 4 * h;          // the row this lane ends up with
+        const bool row_ok = m < p.M;
+        const size_t rowoff = ((size_t)b * Cout + min(m, p.M - 1)) * Tout;
+        const float bias = p.bias ? p.bias[min(m, p.M - 1)] : 0.0f;
+        f32x4 rv[TN], av[TN];
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+          const int n0 = col_base + nt * 32 + jb;
+          const bool ok = row_ok && n0 < T;
+          rv[nt] = (ok && p.res) ? *reinterpret_cast<const f32x4*>(p.res + rowoff + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+          av[nt] = (ok && p.accum) ? *reinterpret_cast<const f32x4*>(p.y + rowoff + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+          float t4[4] = {acc[mt][nt][4 * grp], acc[mt][nt][4 * grp + 1], acc[mt][nt][4 * grp + 2], acc[mt][nt][4 * grp + 3]};
+          quad_transpose4(t4, j);
+          const int n0 = col_base + nt * 32 + jb;
+          if (!row_ok || n0 >= T) continue;
+          f32x4 v;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float e = (t4[c] + bias + rv[nt][c]) * p.scale;
+            if ((size_t)(n0 + c) >= own_len) e = 0.0f;
+            v[c] = e + av[nt][c];
+          }
+          *reinterpret_cast<f32x4*>(p.y + rowoff + n0) = v;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < TM; ++mt) {
 #pragma unroll
