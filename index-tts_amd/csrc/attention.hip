@@ -428,11 +428,20 @@ __global__ __launch_bounds__(256) void flash_attn_bf16x3_kernel(const AttnArgs p
 #define ATT_GLDS16(gptr, lptr) \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
+#ifdef ATT_TIMING
+__device__ long long att_trace[4 * 4096];
+extern "C" int idxtts_debug_att_trace(long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(att_trace), sizeof(long long) * n);
+}
+#endif
 constexpr int ATT_SLOT = 16 * 1024;       // 16 pieces of 1 KiB: [K hi, K lo, V hi, V lo] x 4 chunks
 constexpr int ATT_NSLOT = 3;
+#ifndef DBG_PAD
+#define DBG_PAD 0
+#endif
 
 __global__ __launch_bounds__(256) void flash_attn_planes_kernel(const AttnPlanesArgs p) {
-  __shared__ __attribute__((aligned(1024))) char smem[ATT_NSLOT * ATT_SLOT];
+  __shared__ __attribute__((aligned(1024))) char smem[ATT_NSLOT * ATT_SLOT + DBG_PAD];
 
   const int qblk = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -441,6 +450,9 @@ __global__ __launch_bounds__(256) void flash_attn_planes_kernel(const AttnPlanes
   const int qi = q0 + j;
   const int kend = p.kend ? min(p.kend[b], p.T) : p.T;
   const int ntiles = (kend + 31) >> 5;
+#ifdef ATT_TIMING
+  const long long r_kernel = __builtin_amdgcn_s_memrealtime();
+#endif
   const __bf16* const hi = static_cast<const __bf16*>(p.planes);
   const __bf16* const lo = hi + plane_elems(p.Mrows, p.ncols);
   const size_t rows16 = (size_t)p.Mrows * 16;
@@ -456,22 +468,29 @@ __global__ __launch_bounds__(256) void flash_attn_planes_kernel(const AttnPlanes
       ql[c] = *reinterpret_cast<const bf16x8*>(lo + base + c * rows16);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on only the tile DMAs are in flight: counted waits below
-
-  // DMA role: wave 0 K hi, 1 K lo, 2 V hi, 3 V lo; lane = (LDS row lrow, LDS half unit) of each of the wave's four chunk pieces
-  const int lrow = lane >> 1;
-  const int src_half = (lane & 1) ^ ((lrow >> 3) & 1);
-  const __bf16* const plane = (wave & 1) ? lo : hi;
-  const size_t cbase = (size_t)(((wave < 2 ? p.k_col : p.v_col) >> 4) + hd * 4) * rows16 + src_half * 8;
-  const size_t row_b = (size_t)b * p.T;
-  auto issue_tile = [&](int tile) {
-    char* dst = smem + (tile % ATT_NSLOT) * ATT_SLOT + wave * 4096;
+  // The fragments are consumed here, before the first tile DMA is issued: the compiler places its own wait for the loads now and
+  // knows them complete inside the loop.  (With only a hand-written s_waitcnt it kept them "pending" in its counter model and,
+  // since DMAs are issued after them, drained vmcnt(0) before the first MFMA of EVERY tile -- the prefetch ring was worth nothing.)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int key = tile * 32 + (lrow ^ (4 * (c & 1)));
-      const size_t grow = min(row_b + key, (size_t)p.Mrows - 1);      // keys past the row's end: finite rows of a neighbour, masked below
-      ATT_GLDS16(plane + cbase + c * rows16 + grow * 16, dst + c * 1024);
-    }
+  for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(qh[c]), "+v"(ql[c]));
+
+  // DMA role: wave 0 K hi, 1 K lo, 2 V hi, 3 V lo; lane = (LDS row lrow, LDS half unit) of each of the wave's four chunk pieces.
+  // Addresses: a wave-uniform 64-bit base per chunk (scalar registers) + a 32-bit per-lane byte offset, two offsets per tile (even
+  // and odd chunks differ in the row permutation only) -- the per-tile address arithmetic is six vector instructions.
+  const int lrow = lane >> 1;
+  const unsigned half_b = (unsigned)(((lane & 1) ^ ((lrow >> 3) & 1)) * 16);
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const char* const src0 = reinterpret_cast<const char*>(((wave_s & 1) ? lo : hi) + (size_t)(((wave_s < 2 ? p.k_col : p.v_col) >> 4) + hd * 4) * rows16);
+  const size_t chunk_bytes = rows16 * sizeof(__bf16);
+  const unsigned row_e = (unsigned)(b * p.T + lrow), row_o = (unsigned)(b * p.T + (lrow ^ 4));
+  const unsigned last_row = (unsigned)p.Mrows - 1;
+  auto issue_tile = [&](int tile) {
+    char* dst = smem + (tile % ATT_NSLOT) * ATT_SLOT + wave_s * 4096;
+    // keys past the row's end: finite rows of a neighbour, masked below
+    const unsigned off_e = min(row_e + (unsigned)tile * 32u, last_row) * 32u + half_b;
+    const unsigned off_o = min(row_o + (unsigned)tile * 32u, last_row) * 32u + half_b;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ATT_GLDS16(src0 + c * chunk_bytes + ((c & 1) ? off_o : off_e), dst + c * 1024);
   };
 
   f32x16 o[2];
@@ -492,6 +511,15 @@ __global__ __launch_bounds__(256) void flash_attn_planes_kernel(const AttnPlanes
   const int v_off_a = 2 * 4096 + g1 * 1024 + vL * 32 + ((vp >> 1) << 4) + ((vp & 1) << 3);            // keys 16 t2 + [0, 8): L & 8 == 0
   const int v_off_b = 2 * 4096 + g1 * 1024 + (vL + 8) * 32 + (((vp >> 1) ^ 1) << 4) + ((vp & 1) << 3);   // keys 16 t2 + [8, 16)
 
+#ifdef ATT_TIMING
+  long long tacc[5] = {0, 0, 0, 0, 0};
+#define ATT_T(i) { const long long tn = __builtin_readcyclecounter(); tacc[i] += tn - tprev; tprev = tn; }
+  long long tprev = __builtin_readcyclecounter();
+  const long long t_begin = tprev, r_begin = __builtin_amdgcn_s_memrealtime();
+#else
+#define ATT_T(i)
+#endif
+  const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   if (ntiles > 0) issue_tile(0);
   if (ntiles > 1) issue_tile(1);
   for (int tile = 0; tile < ntiles; ++tile) {
@@ -501,8 +529,11 @@ __global__ __launch_bounds__(256) void flash_attn_planes_kernel(const AttnPlanes
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    ATT_T(0)
     if (tile + 2 < ntiles) issue_tile(tile + 2);
+    ATT_T(1)
     const char* tb = smem + (tile % ATT_NSLOT) * ATT_SLOT;
+    const unsigned slot_lds = smem_lds + (tile % ATT_NSLOT) * ATT_SLOT;
     const int key0 = tile * 32;
     if (q0 < p.Sq) {      // wave-uniform
       // ---- S^T = K . Q^T ----
@@ -518,6 +549,19 @@ __global__ __launch_bounds__(256) void flash_attn_planes_kernel(const AttnPlanes
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[c], s, 0, 0, 0);
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[c], s, 0, 0, 0);
       }
+      ATT_T(2)
+      // V fragments: requested now, behind the QK MFMAs, so that they have landed by the time the softmax is through.
+        const unsigned va = slot_lds + v_off_a, vb = slot_lds + v_off_b;
+        bf16x4 vf[2][2][4];      // [t2][t][hi a, hi b, lo a, lo b]
+#define ATT_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define ATT_TR4(t2, t)                                       \
+        ATT_TR(vf[t2][t][0], va, 512 * t2 + 2048 * t);        \
+        ATT_TR(vf[t2][t][1], vb, 512 * t2 + 2048 * t);        \
+        ATT_TR(vf[t2][t][2], va, 512 * t2 + 2048 * t + 4096); \
+        ATT_TR(vf[t2][t][3], vb, 512 * t2 + 2048 * t + 4096);
+        ATT_TR4(0, 0) ATT_TR4(0, 1) ATT_TR4(1, 0) ATT_TR4(1, 1)
+#undef ATT_TR4
+#undef ATT_TR
       // ---- mask (last tile only) + online softmax in the log2 domain, scale folded into the exponent ----
       if (key0 + 32 > kend) {
 #pragma unroll
@@ -558,25 +602,40 @@ __global__ __launch_bounds__(256) void flash_attn_planes_kernel(const AttnPlanes
         ph[t2] = __builtin_shufflevector(ah, ch, 0, 1, 2, 3, 4, 5, 6, 7);
         pl[t2] = __builtin_shufflevector(al, cl, 0, 1, 2, 3, 4, 5, 6, 7);
       }
+      ATT_T(3)
       // ---- O^T += V^T . P^T ----
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const char* va = tb + 16 * t2 * 32 + t * 2048;
-          typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-          const bf16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(va + v_off_a));
-          const bf16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(va + v_off_b));
-          const bf16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(va + 4096 + v_off_a));
-          const bf16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(va + 4096 + v_off_b));
-          const bf16x8 vh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-          const bf16x8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[t2], o[t], 0, 0, 0);
-          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[t2], o[t], 0, 0, 0);
-          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[t2], o[t], 0, 0, 0);
+      // The transposing reads are issued by hand: the compiler models the ds_read_tr intrinsic as an LDS access that may collide with
+      // the LDS-DMA writes in flight and drains vmcnt(0) before it -- the tile just requested would be waited for in every iteration.
+      // (Its own lgkmcnt bookkeeping does not see these reads; extra outstanding LDS reads only make its counted waits stricter.)
+      {
+#define ATT_PV(t2, t)                                                                              \
+        {                                                                                          \
+          const bf16x8 vh = __builtin_shufflevector(vf[t2][t][0], vf[t2][t][1], 0, 1, 2, 3, 4, 5, 6, 7); \
+          const bf16x8 vl = __builtin_shufflevector(vf[t2][t][2], vf[t2][t][3], 0, 1, 2, 3, 4, 5, 6, 7); \
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[t2], o[t], 0, 0, 0);                \
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[t2], o[t], 0, 0, 0);                \
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[t2], o[t], 0, 0, 0);                \
         }
+#define ATT_WAIT4(n, t2, t) \
+        asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(vf[t2][t][0]), "+v"(vf[t2][t][1]), "+v"(vf[t2][t][2]), "+v"(vf[t2][t][3])::"memory")
+        ATT_WAIT4(12, 0, 0); ATT_PV(0, 0)
+        ATT_WAIT4(8, 0, 1);  ATT_PV(0, 1)
+        ATT_WAIT4(4, 1, 0);  ATT_PV(1, 0)
+        ATT_WAIT4(0, 1, 1);  ATT_PV(1, 1)
+#undef ATT_WAIT4
+#undef ATT_PV
+      }
+      ATT_T(4)
     }
   }
+#ifdef ATT_TIMING
+  const long long r_loop_end = __builtin_amdgcn_s_memrealtime();
+  long long tsave[5] = {tacc[0], tacc[1], tacc[2], tacc[3], tacc[4]};
+  const long long t_loop = (long long)__builtin_readcyclecounter() - t_begin;
+#endif
+#if 0
+    printf("att wave %d tiles %d: wait+barrier %lld issue %lld qk %lld softmax %lld pv %lld | memtime %lld realtime(100MHz) %lld\n", wave, ntiles, tacc[0] / ntiles, tacc[1] / ntiles,
+#endif
 
   const float l_tot = xor32_sum(l_run);
   const float inv_l = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
@@ -609,6 +668,20 @@ __global__ __launch_bounds__(256) void flash_attn_planes_kernel(const AttnPlanes
       }
     }
   }
+#ifdef ATT_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const long long r_end = __builtin_amdgcn_s_memrealtime();
+  if (tid == 0) {
+    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (wg < 4096) {
+      att_trace[4 * wg] = r_kernel; att_trace[4 * wg + 1] = r_end; att_trace[4 * wg + 2] = ((long long)xcc << 32) | hwid;
+      att_trace[4 * wg + 3] = t_loop + tsave[0] * 0;
+    }
+  }
+#endif
 }
 
 int flash_attn_planes_forward(const AttnPlanesArgs& a, hipStream_t stream) {
@@ -618,6 +691,7 @@ int flash_attn_planes_forward(const AttnPlanesArgs& a, hipStream_t stream) {
   IDX_CHECK((a.ncols & 15) == 0 && (a.q_col & 15) == 0 && (a.k_col & 15) == 0 && (a.v_col & 15) == 0, "columns must be multiples of 16");
   IDX_CHECK(std::max(a.q_col, std::max(a.k_col, a.v_col)) + a.H * 64 <= a.ncols, "columns out of range");
   IDX_CHECK((reinterpret_cast<uintptr_t>(a.planes) & 15) == 0, "planes must be 16-byte aligned");
+  IDX_CHECK(a.Mrows < (1 << 26), "rows: per-lane byte offsets are 32-bit");
   dim3 grid(cdiv(a.Sq, 128), a.H, a.B);
   const double flops = 4.0 * a.B * a.H * (double)a.Sq * a.T * 64;
   const double bytes = 4.0 * a.B * a.H * 64.0 * (2.0 * a.Sq + 2.0 * a.T);
