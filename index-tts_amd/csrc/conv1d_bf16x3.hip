@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, (TM == 3 ? 2 : 3)) void conv1d_bf16x3_kernel(c
   // x loader role: channels 4cg..4cg+3 of the chunk, tile rows tq + 64*jj
   const int cg = tid & 3, tq = tid >> 2;
   float xr[NXJ][4];
-  f32x4 wr[NWL];
+  f32x4 wra[NWL], wrb[NWL];      // two weight tiles in flight: the tile of step it + 2 is requested while step it + 1's is stored
 
   auto load_x = [&](int chunk) {
 #pragma unroll
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, (TM == 3 ? 2 : 3)) void conv1d_bf16x3_kernel(c
       }
     }
   };
-  auto load_w = [&](int chunk, int tap) {
+  auto load_w = [&](f32x4 (&wr)[NWL], int chunk, int tap) {
 #pragma unroll
     for (int l = 0; l < NWL; ++l) {
       const int idx = tid + l * 256;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256, (TM == 3 ? 2 : 3)) void conv1d_bf16x3_kernel(c
       wr[l] = v;
     }
   };
-  auto store_w = [&](int buf) {
+  auto store_w = [&](const f32x4 (&wr)[NWL], int buf) {
     char* dst = Ws + buf * NSUB * 2048;
 #pragma unroll
     for (int l = 0; l < NWL; ++l) {
@@ -169,21 +169,31 @@ __global__ __launch_bounds__(256, (TM == 3 ? 2 : 3)) void conv1d_bf16x3_kernel(c
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
 
+  // Prefetch distances: a weight tile is requested TWO steps ahead of its use (a step is 12 MFMAs per wave, ~400 cycles: less than one
+  // L2 round trip under load, so a distance of one step stalled every step on its own load), the x tile of the next chunk at the first
+  // tap of the current one (stored to the other LDS buffer at the last tap).
+  const int total = p.nchunk * p.K;
+  auto step_of = [&](int it, int& c, int& t) { c = it / p.K; t = it - c * p.K; };
   load_x(0);
-  load_w(0, 0);
+  load_w(wra, 0, 0);
   store_x(0);
-  store_w(0);
+  store_w(wra, 0);
+  if (total > 1) { int c1, t1; step_of(1, c1, t1); load_w(wra, c1, t1); }
   __syncthreads();
 
-  const int total = p.nchunk * p.K;
   int chunk = 0, tap = 0;
-  for (int it = 0; it < total; ++it) {
+  // one step: MFMAs of (chunk, tap) from LDS buffer it & 1; w_next holds step it + 1's tile (stored at the end), w_far receives it + 2's
+  auto step = [&](int it, f32x4 (&w_next)[NWL], f32x4 (&w_far)[NWL]) {
     int nchunk_i = chunk, ntap = tap + 1;
     if (ntap == p.K) { ntap = 0; nchunk_i = chunk + 1; }
     const bool has_next = it + 1 < total;
-    const bool next_x = has_next && ntap == 0;
-    if (has_next) load_w(nchunk_i, ntap);
-    if (next_x) load_x(nchunk_i);
+    if (it + 2 < total) {
+      int c2 = nchunk_i, t2 = ntap + 1;
+      if (t2 == p.K) { t2 = 0; c2 = nchunk_i + 1; }
+      load_w(w_far, c2, t2);
+    }
+    const bool x_ahead = p.K > 1 ? (tap == 0 && chunk + 1 < p.nchunk) : has_next;
+    if (x_ahead) load_x(chunk + 1);
 
     {
       const char* xb = Xs + (chunk & 1) * 2 * XPLANE;
@@ -212,11 +222,15 @@ __global__ __launch_bounds__(256, (TM == 3 ? 2 : 3)) void conv1d_bf16x3_kernel(c
         }
     }
 
-    if (has_next) store_w((it + 1) & 1);
-    if (next_x) store_x(nchunk_i & 1);
+    if (has_next) store_w(w_next, (it + 1) & 1);
+    if (has_next && ntap == 0) store_x(nchunk_i & 1);
     __syncthreads();
     chunk = nchunk_i;
     tap = ntap;
+  };
+  for (int it = 0; it < total; it += 2) {
+    step(it, wra, wrb);
+    if (it + 1 < total) step(it + 1, wrb, wra);
   }
 
   // ---- epilogue: bias, residual, scale, (accumulate), store: operands requested in batches ahead of the stores (conv_epilogue.h) ----
