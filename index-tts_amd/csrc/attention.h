@@ -33,6 +33,7 @@ struct AttnPlanesArgs {
   float scale = 0.125f;
   float* o = nullptr; long o_bs = 0; int o_ts = 0;      // fp32 output rows (batch stride, token stride), or null
   void* o_planes = nullptr;       // and / or planes over rows b * Sq + q, columns head * 64 + d
+  int nqblk = 0;                  // (set by the launcher) query blocks of 128 per (batch row, head) pair
 };
 int flash_attn_planes_forward(const AttnPlanesArgs& a, hipStream_t stream);
 

@@ -443,7 +443,12 @@ constexpr int ATT_NSLOT = 3;
 __global__ __launch_bounds__(256) void flash_attn_planes_kernel(const AttnPlanesArgs p) {
   __shared__ __attribute__((aligned(1024))) char smem[ATT_NSLOT * ATT_SLOT + DBG_PAD];
 
-  const int qblk = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+  // XCD-aware walk: consecutive workgroup ids go to the 8 XCDs round-robin, each with its own L2.  All query blocks of one
+  // (batch row, head) pair read the same K / V planes, so they are given to ONE XCD: pair = 8 * (id / 8 / nq) + id % 8.
+  const int L = blockIdx.x, nq = p.nqblk;
+  const int qx = L >> 3, pair = (qx / nq) * 8 + (L & 7), qblk = qx % nq;
+  if (pair >= p.B * p.H) return;      // whole workgroup (uniform)
+  const int b = pair / p.H, hd = pair - b * p.H;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int h = lane >> 5, j = lane & 31;
   const int q0 = qblk * 128 + wave * 32;
@@ -672,7 +677,7 @@ __global__ __launch_bounds__(256) void flash_attn_planes_kernel(const AttnPlanes
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const long long r_end = __builtin_amdgcn_s_memrealtime();
   if (tid == 0) {
-    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int wg = blockIdx.x;
     unsigned hwid, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -692,11 +697,15 @@ int flash_attn_planes_forward(const AttnPlanesArgs& a, hipStream_t stream) {
   IDX_CHECK(std::max(a.q_col, std::max(a.k_col, a.v_col)) + a.H * 64 <= a.ncols, "columns out of range");
   IDX_CHECK((reinterpret_cast<uintptr_t>(a.planes) & 15) == 0, "planes must be 16-byte aligned");
   IDX_CHECK(a.Mrows < (1 << 26), "rows: per-lane byte offsets are 32-bit");
-  dim3 grid(cdiv(a.Sq, 128), a.H, a.B);
+  AttnPlanesArgs k = a;
+  k.nqblk = cdiv(a.Sq, 128);
+  const long long pairs8 = (long long)cdiv(a.B * a.H, 8) * 8;
+  IDX_CHECK(pairs8 * k.nqblk < (1ll << 31), "grid size");
+  dim3 grid((unsigned)(pairs8 * k.nqblk));
   const double flops = 4.0 * a.B * a.H * (double)a.Sq * a.T * 64;
   const double bytes = 4.0 * a.B * a.H * 64.0 * (2.0 * a.Sq + 2.0 * a.T);
   ProfScope prof(PROF_FLASH_ATTN, stream, flops, bytes);
-  hipLaunchKernelGGL(flash_attn_planes_kernel, grid, dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(flash_attn_planes_kernel, grid, dim3(256), 0, stream, k);
   IDX_LAUNCH_CHECK();
   return 0;
 }
