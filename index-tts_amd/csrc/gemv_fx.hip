@@ -266,10 +266,15 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int j = 0; j < NTW; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // Every load of a batch is issued unconditionally, at a clamped chunk index; chunks past this wave's slice are zeroed on the
+  // ACTIVATION side when they are consumed.  (A per-element "load or zero" made the compiler branch around each load, and one of
+  // the merges became a register copy behind an s_waitcnt vmcnt(0) in the middle of the batch: the last three loads of five were
+  // issued only after the first two had come back.)
+  const int c0c = min(c0, p.kc16 - 1), last = max(nch - 1, 0);
   const wraw_t* wbase[NTW];      // one raw element = this lane's 4 weights of a chunk; 64 per chunk
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) wbase[j] = static_cast<const wraw_t*>(p.wp) + ((size_t)min(nt0 + j, p.ntiles - 1) * p.kc16 + c0) * 64 + lane;
-  const float* xbase = p.xf + (size_t)c0 * 256 + (R4 ? ((lane & 48) | (lane & 3)) : lane) * 4;
+  for (int j = 0; j < NTW; ++j) wbase[j] = static_cast<const wraw_t*>(p.wp) + ((size_t)min(nt0 + j, p.ntiles - 1) * p.kc16 + c0c) * 64 + lane;
+  const float* xbase = p.xf + (size_t)c0c * 256 + (R4 ? ((lane & 48) | (lane & 3)) : lane) * 4;
   const size_t ximg = (size_t)p.kc16 * 256;
 
   wraw_t wq[NB][UN][NTW];
@@ -277,13 +282,11 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
   auto load_batch = [&](int buf, int cb) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const bool ok = cb + u < nch;
+      const size_t idx = (size_t)min(cb + u, last);
 #pragma unroll
-      for (int j = 0; j < NTW; ++j)
-        wq[buf][u][j] = ok ? __builtin_nontemporal_load(wbase[j] + (size_t)(cb + u) * 64) : WRaw<WT>::zero();
+      for (int j = 0; j < NTW; ++j) wq[buf][u][j] = __builtin_nontemporal_load(wbase[j] + idx * 64);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        xq[buf][u][mt] = (ok && !(p.dbg & 1)) ? *reinterpret_cast<const f32x4*>(xbase + mt * ximg + (size_t)(cb + u) * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int mt = 0; mt < MT; ++mt) xq[buf][u][mt] = *reinterpret_cast<const f32x4*>(xbase + mt * ximg + idx * 256);
     }
   };
   // shifted row sums for the folded LayerNorm: this lane holds row (lane & 15) of every fragment
@@ -299,6 +302,10 @@ __global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
   auto consume = [&](int buf, int cb) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
+      if (!(cb + u < nch) || (p.dbg & 1)) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xq[buf][u][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
       if (ln && cb + u < nch) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
