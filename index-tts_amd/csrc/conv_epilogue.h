@@ -34,40 +34,69 @@ __device__ __forceinline__ void conv_epilogue(const P& p, f32x16 (&acc)[TM][TN],
   // Wide form (plain convolutions over rows of a multiple of 4 samples, 16-byte aligned tensors): the four accumulator registers of a
   // group are four consecutive ROWS of one column; a quad transpose turns them into four consecutive COLUMNS of one row per lane, so the
   // residual / accumulate reads and the store are 16 bytes per lane -- a quarter of the memory instructions, eight 128-byte runs each.
-  const bool wide = u_log2 == 0 && (T & 3) == 0 && (reinterpret_cast<uintptr_t>(p.y) & 15) == 0 &&
+  const bool wide = u_log2 == 0 && (T & 3) == 0 && T >= 4 && (reinterpret_cast<uintptr_t>(p.y) & 15) == 0 &&
                     (!p.res || (reinterpret_cast<uintptr_t>(p.res) & 15) == 0);
   if (wide) {
     const int lane_q = j & 3, jb = j & ~3;
+    const int tmax = T - 4;      // (T % 4 == 0, T >= 4): a column group past the row's end reads the last one instead; never stored
+    constexpr int GB = TN <= 2 ? 4 : 2;      // row groups per batch: 8 (x 2) 16-byte loads in flight per lane
 #pragma unroll
-    for (int mt = 0; mt < TM; ++mt) {
+    for (int mg = 0; mg < TM * (4 / GB); ++mg) {
+      const int mt = mg / (4 / GB), g0 = (mg % (4 / GB)) * GB;
+      // every residual / accumulate operand of this batch of rows is requested before its first store (a load behind a store to the
+      // same tensor waits for that store): one round trip per batch instead of one per row group.
+      // The loads are branch-free (clamped addresses; rows / columns outside the tile are dropped at the store).
+      f32x4 rv[GB][TN], av[GB][TN];
+      size_t rowoff[GB];
 #pragma unroll
-      for (int grp = 0; grp < 4; ++grp) {
-        const int m = row_base + mt * 32 + lane_q + 8 * grp + 4 * h;          // the row this lane ends up with
+      for (int grp = 0; grp < GB; ++grp) {
+        const int m = row_base + mt * 32 + lane_q + 8 * (g0 + grp) + 4 * h;          // the row this lane ends up with
+        rowoff[grp] = ((size_t)b * Cout + min(m, p.M - 1)) * Tout;
+      }
+      if (p.res) {
+#pragma unroll
+        for (int grp = 0; grp < GB; ++grp)
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt)
+            rv[grp][nt] = *reinterpret_cast<const f32x4*>(p.res + rowoff[grp] + min(col_base + nt * 32 + jb, tmax));
+      } else {
+#pragma unroll
+        for (int grp = 0; grp < GB; ++grp)
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt) rv[grp][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (p.accum) {
+#pragma unroll
+        for (int grp = 0; grp < GB; ++grp)
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt)
+            av[grp][nt] = *reinterpret_cast<const f32x4*>(p.y + rowoff[grp] + min(col_base + nt * 32 + jb, tmax));
+      } else {
+#pragma unroll
+        for (int grp = 0; grp < GB; ++grp)
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt) av[grp][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int grp = 0; grp < GB; ++grp) {
+        const int m = row_base + mt * 32 + lane_q + 8 * (g0 + grp) + 4 * h;
         const bool row_ok = m < p.M;
-        const size_t rowoff = ((size_t)b * Cout + min(m, p.M - 1)) * Tout;
         const float bias = p.bias ? p.bias[min(m, p.M - 1)] : 0.0f;
-        f32x4 rv[TN], av[TN];
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt) {
-          const int n0 = col_base + nt * 32 + jb;
-          const bool ok = row_ok && n0 < T;
-          rv[nt] = (ok && p.res) ? *reinterpret_cast<const f32x4*>(p.res + rowoff + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
-          av[nt] = (ok && p.accum) ? *reinterpret_cast<const f32x4*>(p.y + rowoff + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int nt = 0; nt < TN; ++nt) {
-          float t4[4] = {acc[mt][nt][4 * grp], acc[mt][nt][4 * grp + 1], acc[mt][nt][4 * grp + 2], acc[mt][nt][4 * grp + 3]};
+          const int ga = g0 + grp;
+          float t4[4] = {acc[mt][nt][4 * ga], acc[mt][nt][4 * ga + 1], acc[mt][nt][4 * ga + 2], acc[mt][nt][4 * ga + 3]};
           quad_transpose4(t4, j);
           const int n0 = col_base + nt * 32 + jb;
           if (!row_ok || n0 >= T) continue;
           f32x4 v;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            float e = (t4[c] + bias + rv[nt][c]) * p.scale;
+            float e = (t4[c] + bias + rv[grp][nt][c]) * p.scale;
             if ((size_t)(n0 + c) >= own_len) e = 0.0f;
-            v[c] = e + av[nt][c];
+            v[c] = e + av[grp][nt][c];
           }
-          *reinterpret_cast<f32x4*>(p.y + rowoff + n0) = v;
+          *reinterpret_cast<f32x4*>(p.y + rowoff[grp] + n0) = v;
         }
       }
     }
