@@ -340,6 +340,23 @@ class IndexTTS2:
                 emo_vector = [int(x * scale * 10000) / 10000 for x in emo_vector]
             emo_alpha = 1.0                                                                          # 610-615: the speaker prompt serves
         from .prompt import PromptAudio
+        import os as _os
+        if isinstance(spk_audio_prompt, (str, _os.PathLike)):
+            # file path, as the reference takes it (infer_v2.py:628-630, 685): read, cut to 15 s, resample on the host
+            # (indextts_amd/audioio.py); loaded once per path like cache_spk_audio_prompt / cache_emo_audio_prompt (618, 681)
+            from .audioio import load_prompt_audio
+            files = getattr(self, "_prompt_files", None)
+            if files is None:
+                files = self._prompt_files = {}
+            skey = ("spk", _os.fspath(spk_audio_prompt))
+            if skey not in files:
+                files[skey] = load_prompt_audio(skey[1])
+            spk_audio_prompt = files[skey]
+            if isinstance(emo_audio_prompt, (str, _os.PathLike)):
+                ekey = ("emo", _os.fspath(emo_audio_prompt))
+                if ekey not in files:
+                    files[ekey] = load_prompt_audio(ekey[1], emotion=True)
+                emo_audio_prompt = files[ekey]
         if isinstance(spk_audio_prompt, PromptAudio):
             # audio path: w2v-bert / semantic codec / CAMPPlus / mel / length regulator on the GPU (indextts_amd/prompt.py), cached per
             # prompt object like the reference's cache_spk_cond / cache_emo_cond (infer_v2.py:618, 681)
@@ -373,7 +390,7 @@ class IndexTTS2:
         elif emo_audio_prompt is not None or emo_vector is not None:
             raise NotImplementedError("with a ready PromptConditioning the emotion prompt / vector is already folded into emo_vec")
         if not isinstance(spk_audio_prompt, PromptConditioning):
-            raise NotImplementedError("pass a PromptAudio (resampled waveforms; needs tts.prompt_encoders), PromptFeatures or a PromptConditioning: "
+            raise NotImplementedError("pass a wav file path or a PromptAudio (both need tts.prompt_encoders), PromptFeatures or a PromptConditioning: "
                                       "reading and resampling audio files is left to the caller (librosa / torchaudio are not in this image)")
         segs = text if (len(text) and isinstance(text[0], (list, tuple, np.ndarray, torch.Tensor))) else [text]
         segs = [torch.as_tensor(s, dtype=torch.long).reshape(1, -1) for s in segs]

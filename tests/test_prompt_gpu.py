@@ -105,3 +105,39 @@ def test_infer_takes_the_prompt_audio(device, rig):
     torch.manual_seed(3)
     _, b = tts.infer(enc.encode(spk, emo), seg, None, emo_alpha=0.7, **G)
     assert sr == 22050 and a.dtype == np.int16 and np.array_equal(a, b)
+
+
+def test_infer_takes_wav_file_paths(device, rig, tmp_path):
+    """`infer(spk_audio_prompt="speaker.wav", emo_audio_prompt="emotion.wav")` as the reference is called (infer_v2.py:628-630, 685):
+    the files are read, cut and resampled on the host (indextts_amd/audioio.py) and give the same waveform as the PromptAudio built
+    from the same samples by hand."""
+    import wave
+    from indextts_amd import audioio
+    from indextts_amd.prompt import PromptAudio
+    cfg, wcfg, ccfg, pcfg, ws, ww, wc, wp, tts, enc = rig
+    tts.prompt_encoders = enc
+
+    def write(path, x, sr):
+        with wave.open(str(path), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr)
+            w.writeframes((np.clip(x, -1, 1) * 32767).astype("<i2").tobytes())
+
+    write(tmp_path / "spk.wav", _audio("t/prompt/f22", 22050, 2.4), 22050)      # at librosa's default rate: no first-stage resampling
+    write(tmp_path / "emo.wav", _audio("t/prompt/f24", 24000, 1.5), 24000)      # resampled to 16 kHz by the loader
+    seg = synth.integers("t/prompt/seg", (2, 6), 2, cfg.gpt.number_text_tokens).tolist()
+    G = dict(do_sample=False, num_beams=1, max_mel_tokens=16)
+    import warnings
+    warnings.simplefilter("ignore")
+    torch.manual_seed(5)
+    sr, a = tts.infer(str(tmp_path / "spk.wav"), seg, None, emo_audio_prompt=str(tmp_path / "emo.wav"), emo_alpha=0.6, **G)
+    files = dict(tts._prompt_files)
+    torch.manual_seed(5)
+    _, a2 = tts.infer(str(tmp_path / "spk.wav"), seg, None, emo_audio_prompt=str(tmp_path / "emo.wav"), emo_alpha=0.6, **G)
+    assert all(tts._prompt_files[k] is v for k, v in files.items()) and np.array_equal(a, a2)      # each file was read once
+    x22, r = audioio.load_and_cut_audio(str(tmp_path / "spk.wav"), 15)
+    assert r == 22050
+    spk = PromptAudio(audioio.sinc_resample(x22, 22050, 16000)[0], x22[0])
+    emo = PromptAudio(audioio.load_and_cut_audio(str(tmp_path / "emo.wav"), 15, sr=16000)[0][0])
+    torch.manual_seed(5)
+    _, b = tts.infer(spk, seg, None, emo_audio_prompt=emo, emo_alpha=0.6, **G)
+    assert sr == 22050 and a.dtype == np.int16 and np.array_equal(a, b)
