@@ -1,3 +1,6 @@
+"""Per-launch time of the DiT planes attention at the bench shape (B = 32 with CFG -> 64 rows, T = 1130, prompt 689), by the library's own
+per-launch HIP events: `python tools/attn_time.py` on a GPU box.  With a `-DATT_TIMING` build of csrc/attention.hip the kernel also
+prints per-tile `s_memtime` stamps of one workgroup (wait + barrier / DMA issue / QK / softmax / PV)."""
 import sys, torch
 sys.path.insert(0, "index-tts_amd")
 from indextts_amd import weights, _lib

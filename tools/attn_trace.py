@@ -1,3 +1,6 @@
+"""Per-workgroup timeline of one planes-attention launch: start / end (`s_memrealtime`), XCC and CU of every workgroup, read back through
+`idxtts_debug_att_trace` -- a symbol that exists only in a `-DATT_TIMING` build of csrc/attention.hip (diagnostic; the product library
+does not carry it).  Prints residency per CU, workgroup durations and the dispatch waves (profiles/README.md, last kernel pass)."""
 import sys, ctypes, numpy as np, torch
 sys.path.insert(0, "index-tts_amd")
 from indextts_amd import weights, _lib
