@@ -73,8 +73,10 @@ def test_infer_return_contract(device, tmp_path):
     assert tts.infer(cond, [], None) is None
     with pytest.raises(ValueError):
         list(tts.infer(cond, seg[0], None, stream_return=True, return_audio=True))      # a generator: raises on first use, as the reference
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(FileNotFoundError):              # a path is read like the reference's librosa.load would (audioio.py)
         tts.infer("examples/voice_01.wav", seg[0], None)
+    with pytest.raises(NotImplementedError):            # anything else that is not a prompt
+        tts.infer(object(), seg[0], None)
     with pytest.raises(TypeError):
         tts.infer(cond, seg[0], None, max_mel_tokens=16, no_such_kwarg=1)
     # the reference's sampling kwargs (num_beams=1): seeded draws make the run reproducible, and it differs from greedy
