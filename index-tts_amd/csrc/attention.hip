@@ -428,6 +428,9 @@ __global__ __launch_bounds__(256) void flash_attn_bf16x3_kernel(const AttnArgs p
 #define ATT_GLDS16(gptr, lptr) \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
+// Diagnostic build only (-DATT_TIMING; never in the product library, tests/test_abi.py checks the exported symbols): per-tile
+// s_memtime stamps and a per-workgroup (start, end, XCC | HW_ID, loop cycles) record read back by tools/attn_trace.py.
+// -DDBG_PAD=bytes pads the LDS allocation to lower the occupancy (2 workgroups per CU at 16 KiB, 1 at 40 KiB) for the same study.
 #ifdef ATT_TIMING
 __device__ long long att_trace[4 * 4096];
 extern "C" int idxtts_debug_att_trace(long long* out, int n) {
