@@ -86,86 +86,87 @@ struct GemmV2P {
   GemmKP g;                      // shapes, epilogue operands, conv parameters (x unused)
   const __bf16* a_hi; const __bf16* a_lo;   // [K/16][a_rows][16]
   const __bf16* b_hi; const __bf16* b_lo;   // [K/16][npad][16]
-  const __bf16* zeros;           // >= 32 bytes of zeros (rows outside M / outside the sequence)
   int a_rows, npad, nstages;
+  int a_bytes, b_bytes;          // bytes of the hi + lo planes of each operand (buffer descriptors)
+  int a_plane, b_plane;          // byte offset of the lo plane
 };
 
-#define GLDS16(gptr, lptr) \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+// Workgroup = 4 x 2 waves, each a 64 x 128 output tile (2 x 4 MFMA tiles): 256 x 256 per workgroup, 512 threads, 32 KiB stages,
+// 4-deep ring, one workgroup per CU.
+//
+// Round 3: what a stage's instruction stream holds besides its 24 MFMAs decides the kernel (profiles/README.md "Round 3"):
+//   * every LDS-DMA is ONE buffer_load_dwordx4 ... lds: the lane's byte offset inside the operand planes is a VGPR computed
+//     once per tile (once per tap for the convolution form), the stage offset an SGPR that advances by a constant, the
+//     ring slot goes to M0 -- no vector arithmetic per piece (the per-piece 64-bit address arithmetic of the first form was
+//     ~20 VALU + ~35 SALU instructions, 100-185 issue cycles each time, four times per stage);
+//   * rows outside a convolution's sequence read zeros through the descriptor's range check (offset bit 31 set), rows
+//     beyond M re-read row M - 1 (never stored);
+//   * the counted waits are the compiler's own s_waitcnt (builtin), not inline asm: with the asm form the compiler could not
+//     know that a fragment set had landed and put s_waitcnt lgkmcnt(0) in front of the first MFMA of every stage -- i.e.
+//     BEHIND the 12 fragment reads of the NEXT stage it had just issued, which undid the double-buffered fragment registers.
+struct V2Rsrc { __amdgpu_buffer_rsrc_t a, b; };
 
-template <int N> __device__ __forceinline__ void wait_vm_lgkm0();
-template <> __device__ __forceinline__ void wait_vm_lgkm0<0>() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vm_lgkm0<4>() { asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vm_lgkm0<6>() { asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vm_lgkm0<8>() { asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vm_lgkm0<12>() { asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vm_lgkm0<18>() { asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory"); }
+#define V2_WAITCNT(vm) __builtin_amdgcn_s_waitcnt(((vm) & 15) | (((vm) >> 4) << 14) | 0x70)   /* vmcnt(vm) lgkmcnt(0) */
 
-// Workgroup = 4 x WNW waves, each a 64 x 128 output tile (2 x 4 MFMA tiles): 256 x (128 WNW) per workgroup.
-//   WNW = 2: 512 threads, 32 KiB stages, 4-deep ring, one workgroup per CU;
-//   WNW = 1: 256 threads, 24 KiB stages, 3-deep ring, TWO workgroups per CU -- the waves that share a SIMD then belong to
-//            different workgroups with independent barriers, so one multiplies while the other waits / issues DMA.
-template <int WNW, int NSTAGE>
+template <bool TAPS, int EPI>
 __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, const int bn, const int tid) {
-  constexpr int NWV = 4 * WNW;                 // waves
-  constexpr int BN = 128 * WNW;
-  constexpr int A_PLANE = 256 * 32, B_PLANE = BN * 32;
-  constexpr int STAGE_BYTES = 2 * A_PLANE + 2 * B_PLANE;
-  constexpr int ARB = 8 / NWV, BRB = (BN / 32) / NWV;      // 32-row blocks of A / B a wave copies per plane and stage
-  constexpr int PPW = 2 * (ARB + BRB);                     // DMA instructions per wave and stage
+  constexpr int NSTAGE = 4;
+  constexpr int PLANE = 256 * 32;              // bytes of one operand plane of a stage (256 rows x 32 B)
+  constexpr int STAGE_BYTES = 4 * PLANE;       // [A hi][A lo][B hi][B lo]
+  constexpr int PPW = 4;                       // DMA instructions per wave and stage
   const GemmKP& p = q.g;
   extern __shared__ __attribute__((aligned(1024))) char smv2[];
 
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int h = lane >> 5, j = lane & 31;
-  const int wm = wave / WNW, wn = wave % WNW;
+  const int wm = wave >> 1, wn = wave & 1;
 
-  // ---- DMA role of this lane: row (lane >> 1) of the wave's 32-row blocks, LDS unit lane & 1, source unit swizzled ----
+  // ---- DMA role of this lane: row (lane >> 1) of the wave's 32-row block, LDS unit lane & 1, source unit swizzled ----
   const int lrow = lane >> 1;
   const int dunit = (lane & 1) ^ ((lrow >> 3) & 1);        // block bases are multiples of 32: row bit 3 = lrow bit 3
-  int a_m[ARB], seq_base[ARB], seq_t[ARB], seq_n[ARB];
-#pragma unroll
-  for (int r = 0; r < ARB; ++r) {
-    a_m[r] = bm * 256 + 32 * (wave * ARB + r) + lrow;
-    seq_base[r] = seq_t[r] = seq_n[r] = 0;
-    if (p.taps > 1) {
-      const int sb = a_m[r] / p.seq_len;
-      seq_base[r] = sb * p.seq_len;
-      seq_t[r] = a_m[r] - seq_base[r];
-      seq_n[r] = (p.row_len && a_m[r] < p.M) ? min(p.row_len[sb], p.seq_len) : p.seq_len;
-    }
+  const int a_m = bm * 256 + 32 * wave + lrow;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(q.a_hi), 0, q.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(q.b_hi), 0, q.b_bytes, 0x00020000);
+  const int voffB = (bn * 256 + 32 * wave + lrow) * 32 + dunit * 16;
+  int voffA = min(a_m, q.a_rows - 1) * 32 + dunit * 16;
+  int seq_base = 0, seq_t = 0, seq_n = 0;
+  if (TAPS) {
+    const int sb = a_m / p.seq_len;
+    seq_base = sb * p.seq_len;
+    seq_t = a_m - seq_base;
+    seq_n = (p.row_len && a_m < p.M) ? min(p.row_len[sb], p.seq_len) : p.seq_len;
   }
-
-  // one DMA instruction: piece `pi` (0 .. PPW-1) of stage `st`: [A row blocks: hi, lo] then [B row blocks: hi, lo]
-  auto issue_piece = [&](int st, int pi) {
-    char* sbase = smv2 + (st % NSTAGE) * STAGE_BYTES;
-    if (pi < 2 * ARB) {
-      const int r = pi >> 1, lo = pi & 1;
-      const int blk = wave * ARB + r;
-      size_t o;
-      bool ok = a_m[r] < p.M;
-      if (p.taps > 1) {
-        const int k0 = st * 16;
-        const int tap = k0 / p.kc, ch = (k0 - tap * p.kc) >> 4;
-        int t = seq_t[r] + tap * p.dil - p.pad_left;
-        if (p.pad_mode == 1) { t = t < 0 ? -t : t; t = t >= seq_n[r] ? 2 * (seq_n[r] - 1) - t : t; }
-        ok = ok && t >= 0 && t < seq_n[r];
-        o = ((size_t)ch * q.a_rows + (seq_base[r] + (ok ? t : 0))) * 16 + dunit * 8;
-      } else {
-        o = ((size_t)st * q.a_rows + min(a_m[r], q.a_rows - 1)) * 16 + dunit * 8;
-      }
-      const __bf16* src = ok ? (lo ? q.a_lo : q.a_hi) + o : q.zeros;
-      GLDS16(src, sbase + lo * A_PLANE + blk * 1024);
-    } else {
-      const int pb = pi - 2 * ARB;
-      const int r = pb >> 1, lo = pb & 1;
-      const int blk = wave * BRB + r;
-      const size_t o = ((size_t)st * q.npad + (size_t)bn * BN + 32 * blk + lrow) * 16 + dunit * 8;
-      GLDS16((lo ? q.b_lo : q.b_hi) + o, sbase + 2 * A_PLANE + lo * B_PLANE + blk * 1024);
+  // the lane's A offset for tap `tap` (convolution form): row t = seq_t + tap * dil - pad_left of its own sequence, reflected
+  // or zero outside [0, seq_n)
+  auto tap_voff = [&](int tap) -> int {
+    int t = seq_t + tap * p.dil - p.pad_left;
+    if (p.pad_mode == 1) { t = t < 0 ? -t : t; t = t >= seq_n ? 2 * (seq_n - 1) - t : t; }
+    const bool ok = a_m < p.M && t >= 0 && t < seq_n;
+    return ok ? (seq_base + t) * 32 + dunit * 16 : (int)0x80000000;
+  };
+  const int ns = q.nstages;
+  const int sA = q.a_rows * 32, sB = q.npad * 32;          // bytes between two 16-k chunks of a plane
+  const int cpt = TAPS ? (p.kc >> 4) : ns;                 // chunks per tap
+  // scalar issue state: the next stage to request, its plane offsets, its chunk inside the tap
+  int ist = 0, soA = 0, soB = 0, ich = 0, itap = 0;
+  if (TAPS) voffA = tap_voff(0);
+  char* const lds_w = smv2 + wave * 1024;
+  auto issue_piece = [&](int pi) {           // piece pi of stage ist: A hi, A lo, B hi, B lo
+    auto dst = (__attribute__((address_space(3))) void*)(lds_w + (ist & (NSTAGE - 1)) * STAGE_BYTES + pi * PLANE);
+    if (pi == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, dst, 16, voffA, soA, 0, 0);
+    else if (pi == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, dst, 16, voffA, soA + q.a_plane, 0, 0);
+    else if (pi == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, dst, 16, voffB, soB, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, dst, 16, voffB, soB + q.b_plane, 0, 0);
+  };
+  auto advance = [&]() {
+    ++ist;
+    soB += sB;
+    soA += sA;
+    if (TAPS) {
+      if (++ich == cpt) { ich = 0; soA = 0; ++itap; voffA = tap_voff(itap); }
     }
   };
 
-  const int ns = q.nstages;
   // fragment read offsets (bytes inside a plane image): row * 32 + (h ^ (row >> 3 & 1)) * 16, row = tile row of lane j
   const int sw = (h ^ ((j >> 3) & 1)) * 16;
   const int a_off = (wm * 64 + j) * 32 + sw;          // + t * 1024 for the second 32-row tile
@@ -179,106 +180,121 @@ __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, con
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-#pragma unroll
   for (int s = 0; s < NSTAGE; ++s)
     if (s < ns) {
 #pragma unroll
-      for (int pi = 0; pi < PPW; ++pi) issue_piece(s, pi);
+      for (int pi = 0; pi < PPW; ++pi) issue_piece(pi);
+      advance();
     }
 
   struct Frag { bf16x8 ah[2], al[2], bh[4], bl[4]; };
   // stage s has landed for the whole workgroup: this wave's pieces by the counted wait (younger stages may stay in
   // flight), everyone's by the barrier; the lgkmcnt(0) retires this wave's fragment reads of stage s - 1, so after the
-  // barrier that ring slot may be overwritten
+  // barrier that ring slot may be overwritten.  Stages in flight behind s: min(2, ns - 1 - s) (3 behind stage 0).
   auto wait_stage = [&](int s) {
-    const int issued = min(ns - 1, max(NSTAGE - 1, s + NSTAGE - 2));
-    const int pending = issued - s;
-    if (pending >= 3) wait_vm_lgkm0<3 * PPW>();
-    else if (pending == 2) wait_vm_lgkm0<2 * PPW>();
-    else if (pending == 1) wait_vm_lgkm0<PPW>();
-    else wait_vm_lgkm0<0>();
+    const int rem = ns - 1 - s;
+    if (rem >= 2) V2_WAITCNT(2 * PPW);
+    else if (rem == 1) V2_WAITCNT(PPW);
+    else V2_WAITCNT(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
   auto load_frags = [&](Frag& f, int s) {
-    const char* st = smv2 + (s % NSTAGE) * STAGE_BYTES;
+    const char* st = smv2 + (s & (NSTAGE - 1)) * STAGE_BYTES;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       f.ah[t] = *reinterpret_cast<const bf16x8*>(st + a_off + t * 1024);
-      f.al[t] = *reinterpret_cast<const bf16x8*>(st + A_PLANE + a_off + t * 1024);
+      f.al[t] = *reinterpret_cast<const bf16x8*>(st + PLANE + a_off + t * 1024);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      f.bh[t] = *reinterpret_cast<const bf16x8*>(st + 2 * A_PLANE + b_offr + t * 1024);
-      f.bl[t] = *reinterpret_cast<const bf16x8*>(st + 2 * A_PLANE + B_PLANE + b_offr + t * 1024);
+      f.bh[t] = *reinterpret_cast<const bf16x8*>(st + 2 * PLANE + b_offr + t * 1024);
+      f.bl[t] = *reinterpret_cast<const bf16x8*>(st + 3 * PLANE + b_offr + t * 1024);
     }
   };
   // 24 MFMAs of stage i; the DMA of stage i + NSTAGE (ring slot of stage i, free since the last barrier) is issued
-  // piecewise in their shadow (an LDS-DMA instruction costs ~100-180 issue cycles on its own, little behind an MFMA)
-  auto compute = [&](const Frag& f, int i) {
-    const bool more = i + NSTAGE < ns;
-    const int nst = i + NSTAGE;
-    constexpr int PQ = (PPW + 3) / 4;          // pieces issued after each of the four MFMA groups
-    auto dma = [&](int g) {
-#pragma unroll
-      for (int u = 0; u < PQ; ++u)
-        if (g * PQ + u < PPW) issue_piece(nst, g * PQ + u);
-    };
+  // piecewise between the four MFMA groups
+  auto compute = [&](const Frag& f, const bool more) {
 #define V2_MFMA3(mt, nt)                                                                                         \
     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);             \
     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], f.bl[nt], acc[mt][nt], 0, 0, 0);             \
     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
     V2_MFMA3(0, 0) V2_MFMA3(0, 1)
     __builtin_amdgcn_sched_barrier(0);
-    if (more) dma(0);
+    if (more) issue_piece(0);
     __builtin_amdgcn_sched_barrier(0);
     V2_MFMA3(0, 2) V2_MFMA3(0, 3)
     __builtin_amdgcn_sched_barrier(0);
-    if (more) dma(1);
+    if (more) issue_piece(1);
     __builtin_amdgcn_sched_barrier(0);
     V2_MFMA3(1, 0) V2_MFMA3(1, 1)
     __builtin_amdgcn_sched_barrier(0);
-    if (more) dma(2);
+    if (more) issue_piece(2);
     __builtin_amdgcn_sched_barrier(0);
     V2_MFMA3(1, 2) V2_MFMA3(1, 3)
     __builtin_amdgcn_sched_barrier(0);
-    if (more) dma(3);
+    if (more) { issue_piece(3); advance(); }
     __builtin_amdgcn_sched_barrier(0);
 #undef V2_MFMA3
   };
 
   // two fragment register sets: the reads of stage i + 1 are in flight while stage i is multiplied
   Frag f0, f1;
-  wait_stage(0);
+  {   // stage 0: up to three younger stages in flight
+    const int rem = ns - 1;
+    if (rem >= 3) V2_WAITCNT(3 * PPW);
+    else if (rem == 2) V2_WAITCNT(2 * PPW);
+    else if (rem == 1) V2_WAITCNT(PPW);
+    else V2_WAITCNT(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
   load_frags(f0, 0);
-  for (int i = 0; i < ns; i += 2) {
+  int i = 0;
+  // steady state, straight-line: two younger stages in flight behind every wait, a stage to request beside every compute
+  // (a branch-free body also keeps the compiler's counter model exact: at a join of paths with different numbers of LDS reads
+  // pending it falls back to s_waitcnt lgkmcnt(0) in front of the first MFMA, i.e. behind the next stage's fragment reads)
+  for (; i + 5 < ns; i += 2) {
+    V2_WAITCNT(2 * PPW);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(f1, i + 1);
+    compute(f0, true);
+    V2_WAITCNT(2 * PPW);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(f0, i + 2);
+    compute(f1, true);
+  }
+  for (; i < ns; i += 2) {     // the last stages: the ring drains
     if (i + 1 < ns) { wait_stage(i + 1); load_frags(f1, i + 1); }
-    compute(f0, i);
+    else V2_WAITCNT(0);
+    compute(f0, ist < ns);
     if (i + 1 < ns) {
       if (i + 2 < ns) { wait_stage(i + 2); load_frags(f0, i + 2); }
-      compute(f1, i + 1);
+      else V2_WAITCNT(0);
+      compute(f1, ist < ns);
     }
   }
-  __syncthreads();
-  gemm_epilogue_lds<4, WNW, 2, 4>(p, acc, reinterpret_cast<float*>(smv2), bm * 256, bn * BN, wm, wn, wave, lane);
+  // (the last wait_stage left no DMA in flight; the epilogue synchronises the workgroup itself before it reuses the ring)
+  gemm_epilogue_wave<EPI>(p, acc, reinterpret_cast<float*>(smv2), bm * 256 + wm * 64, bn * 256 + wn * 128, wave, lane);
 }
 
 // one output tile per workgroup; XCD x owns the row tiles == x (mod 8) (gemm.hip explains the two walk orders)
-template <int WNW, int NSTAGE>
-__global__ __launch_bounds__(256 * WNW) void gemm_bf16x3_v2_kernel(const GemmV2P q) {
+template <bool TAPS, int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16x3_v2_kernel(const GemmV2P q) {
   const GemmKP& p = q.g;
   const int L = blockIdx.x, xcd = L & 7, qq = L >> 3;
   int bn, bm;
   if (p.n_fast) { const int bml = qq / p.nblocks; bn = qq - bml * p.nblocks; bm = bml * 8 + xcd; }
   else { bn = qq / p.mt8; bm = (qq - bn * p.mt8) * 8 + xcd; }
   if (bm >= p.mtiles) return;
-  gemm_v2_tile<WNW, NSTAGE>(q, bm, bn, threadIdx.x);
+  gemm_v2_tile<TAPS, EPI>(q, bm, bn, threadIdx.x);
 }
 
 // ---- per-stream scratch for the activation planes (grow-only) ----
 struct PlaneScratch { void* ptr = nullptr; size_t bytes = 0; };
 static std::map<hipStream_t, PlaneScratch> g_scratch;      // guarded by g_scratch_mu: stages of different batches may run on
-static const __bf16* g_zero_page = nullptr;                 // different host threads / streams (bench.py's two-stage pipeline)
 static std::mutex g_scratch_mu;
 
 
@@ -295,12 +311,6 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
     if (sc.ptr) IDX_HIP(hipFree(sc.ptr));
     sc.bytes = 2 * plane + (plane >> 2);
     IDX_HIP(hipMalloc(&sc.ptr, sc.bytes));
-  }
-  if (!g_zero_page) {
-    void* z = nullptr;
-    IDX_HIP(hipMalloc(&z, 4096));
-    IDX_HIP(hipMemset(z, 0, 4096));
-    g_zero_page = static_cast<const __bf16*>(z);
   }
   lock.unlock();
   const __bf16* hi = a.x_planes ? static_cast<const __bf16*>(a.x_planes) : static_cast<const __bf16*>(sc.ptr);
@@ -332,18 +342,34 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
   q.npad = cdiv(w.N, 256) * 256;
   q.b_hi = static_cast<const __bf16*>(wplanes);
   q.b_lo = q.b_hi + (size_t)(w.K / 16) * q.npad * 16;
-  q.zeros = g_zero_page;
   q.nstages = w.K / 16;
+  const size_t b_plane = (size_t)(w.K / 16) * q.npad * 32;
+  IDX_CHECK(2 * plane < (1ull << 31) && 2 * b_plane < (1ull << 31), "operand planes beyond the 2 GiB a buffer offset addresses");
+  q.a_plane = (int)plane; q.a_bytes = (int)(2 * plane);
+  q.b_plane = (int)b_plane; q.b_bytes = (int)(2 * b_plane);
   const int64_t grid = (int64_t)8 * q.g.nblocks * q.g.mt8;
   IDX_CHECK(grid < (1ll << 31), "grid size");
   ProfScope prof(PROF_GEMM_BF16X3_256x256, stream, flops, bytes);
   constexpr int lds = 4 * (2 * 256 * 32 + 2 * 256 * 32);
-  static bool attr_set = false;
-  if (!attr_set) {
-    IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v2_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((gemm_bf16x3_v2_kernel<2, 4>), dim3((unsigned)grid), dim3(512), lds, stream, q);
+  const bool paired = a.act == ACT_SWIGLU || a.act == ACT_GATE;
+  IDX_CHECK(!(a.rope && (a.res || paired)), "the rotary epilogue takes no residual and no paired activation");
+  IDX_CHECK(!a.row_len || a.seq_len >= 16, "row masks need seq_len >= 16");
+  const int epi = a.rope ? EPI_ROPE : paired ? EPI_PAIRED : a.act != ACT_NONE ? EPI_ACT : EPI_PLAIN;
+  typedef void (*KernelFn)(const GemmV2P);
+  static const KernelFn kernels[2][4] = {
+      {gemm_bf16x3_v2_kernel<false, EPI_PLAIN>, gemm_bf16x3_v2_kernel<false, EPI_ROPE>, gemm_bf16x3_v2_kernel<false, EPI_PAIRED>, gemm_bf16x3_v2_kernel<false, EPI_ACT>},
+      {gemm_bf16x3_v2_kernel<true, EPI_PLAIN>, gemm_bf16x3_v2_kernel<true, EPI_ROPE>, gemm_bf16x3_v2_kernel<true, EPI_PAIRED>, gemm_bf16x3_v2_kernel<true, EPI_ACT>}};
+  static std::once_flag attr_once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(attr_once, [&] {
+    for (int t = 0; t < 2; ++t)
+      for (int e = 0; e < 4; ++e) {
+        const hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[t][e]), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (r != hipSuccess) attr_err = r;
+      }
+  });
+  IDX_HIP(attr_err);
+  hipLaunchKernelGGL(kernels[a.taps > 1 ? 1 : 0][epi], dim3((unsigned)grid), dim3(512), lds, stream, q);
   IDX_LAUNCH_CHECK();
   return 0;
 }

@@ -111,122 +111,167 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmKP& p, f32x16 (&acc)[T
   }
 }
 
-// Workgroup epilogue through LDS: the accumulators of one wave-row (a slab of TM*32 rows x BN columns) are transposed
-// through LDS so that every global access of the epilogue is row-contiguous: a lane owns 4 adjacent columns (one 16-byte
-// bias load for the whole tile, 16-byte residual loads and stores; a 256-column row is ONE 1-KiB wave store) and every
-// per-row quantity (bounds, row mask) is wave-uniform.  The direct form above issues TM*TN*16 scattered dword stores per
-// lane from fully unrolled code (tens of thousands of instructions: 40-50 % of a K = 512 GEMM's time on MI355X).
-//   WMW x WNW waves, wave (wm, wn) holds rows wm*TM*32.., packed columns wn*TN*32..; lds: >= TM*32 * (BN + 8) floats.
-// All waves of the workgroup must call it (it synchronises); LDS must not be in use by anyone (no DMA in flight).
-template <int WMW, int WNW, int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmKP& p, f32x16 (&acc)[TM][TN], float* lds, int row_base, int col_base,
-                                                  int wm, int wn, int wave, int lane) {
-  constexpr int BN = WNW * TN * 32, SLAB = TM * 32, NW = WMW * WNW;
-  constexpr int RS = BN + 8;                    // +8 floats: the two row groups a wave writes (h = 0/1: rows +4) land on disjoint banks
-  const bool paired = p.act == ACT_SWIGLU || p.act == ACT_GATE;
+// Hardware-rate activations for the split-bf16 epilogue (errors ~1e-7, far below the 2^-16 of the products before them).
+__device__ __forceinline__ float act_apply_fast(float v, int act) {
+  if (act == ACT_GELU_NEW) return v * sigmoid_fast(1.5957691216057308f * (v + 0.044715f * v * v * v));   // 0.5 v (1 + tanh u) = v sigmoid(2u)
+  if (act == ACT_SILU) return v * sigmoid_fast(v);
+  return act_apply(v, act);
+}
+
+// Epilogue of the LDS-DMA kernel's 256 x 256 tile (8 waves; wave (wm, wn) holds rows wm*64.., packed columns wn*128..), one wave
+// at a time: every wave transposes ITS OWN 64 x 128 accumulator tile through a private 16-row LDS image, four passes of
+// 16 rows, so that every global access is row-contiguous (a lane owns 4 adjacent columns: 16-byte bias / residual loads and
+// stores, 512-byte row segments) and every per-row quantity is uniform over half a wave.  Round 3 (profiles/README.md):
+//   * no workgroup barrier after the first one: the earlier form walked four 64-row slabs with two barriers each, and each slab
+//     was a dependent round trip (residual load -> add -> store) of ~3.5 us: 26 % of a K = 512 tile;
+//   * the residual rows (or the rotary table rows) of THREE passes are requested before the first pass starts -- the fragment
+//     registers of the main loop are dead by then -- and the fourth after the first pass; a residual may alias the output
+//     (in-place h += ...), and a load issued behind a store waits for that store's acknowledgement (vmcnt counts both);
+//   * output planes leave in plane order: a second read of the finished pass (written back in place) hands every lane 8
+//     adjacent columns of one row, 16 rows x 32 bytes of one 16-column chunk are one 512-byte run per plane.
+// EPI selects the body at compile time (the kernel is instantiated per kind; a run-time switch inside 32 unrolled row groups
+// is what made the first form's code tens of thousands of instructions):
+//   EPI_PLAIN   bias, out_scale, residual, row mask          EPI_ROPE    bias, rotary pairs (no residual)
+//   EPI_PAIRED  SwiGLU / tanh-sigmoid gate of packed [gate 32 | linear 32] column groups, residual, row mask
+//   EPI_ACT     any other activation (rolled loops, operands loaded in place: the rare shapes)
+// All waves of the workgroup must call it (one __syncthreads inside, behind the operand requests); `lds_base` = the workgroup's
+// LDS (>= 8 x 16 x 132 floats), no DMA in flight.
+enum { EPI_PLAIN = 0, EPI_ROPE = 1, EPI_PAIRED = 2, EPI_ACT = 3 };
+
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_wave(const GemmKP& p, f32x16 (&acc)[2][4], float* lds_base, const int row0, const int col0,
+                                                   const int wave, const int lane) {
+  constexpr bool PAIRED = EPI == EPI_PAIRED;
+  constexpr bool PREF = EPI != EPI_ACT;         // residual / rotary rows prefetched into registers
+  constexpr int RS = 132;                       // floats per LDS row: 128 + 4 (row r + 1 starts one 16-byte slot further)
+  constexpr int LPR = PAIRED ? 16 : 32;         // lanes per row
+  constexpr int RPI = 64 / LPR;                 // rows per wave-instruction
+  constexpr int NIT = 16 / RPI;                 // instructions per 16-row pass
+  float* const lds = lds_base + wave * (16 * RS);
   const int h = lane >> 5, j = lane & 31;
-  const bool vec_ok = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) &&
-                      (!p.res || (((p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0)));
-  for (int slab = 0; slab < WMW; ++slab) {
-    __syncthreads();
-    if (wm == slab) {
+  const int sub = lane / LPR, c = lane % LPR;
+  int n_out, nb0, nb1 = 0, lcol, ocol;          // output column, bias columns, LDS column read, LDS column of the finished value
+  if (PAIRED) {
+    const int g = c >> 3, cc = (c & 7) * 4;     // 64-column packed group [gate 32 | linear 32], offset inside its 32 outputs
+    nb0 = col0 + g * 64 + cc; nb1 = nb0 + 32;
+    n_out = ((col0 + g * 64) >> 1) + cc;
+    lcol = g * 64 + cc; ocol = g * 32 + cc;
+  } else {
+    nb0 = col0 + c * 4; n_out = nb0; lcol = c * 4; ocol = lcol;
+  }
+  const int n_lim = PAIRED ? (p.N >> 1) : p.N;
+  const bool col_ok = nb0 < p.N;
+  const bool vec = col_ok && n_out + 3 < n_lim && ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) &&
+                   (!p.res || (((p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0)));
+  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+  if (p.bias && col_ok) {
 #pragma unroll
-      for (int mt = 0; mt < TM; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < TN; ++nt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            lds[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * RS + wn * TN * 32 + nt * 32 + j] = acc[mt][nt][r];
+    for (int e = 0; e < 4; ++e) {
+      if (nb0 + e < p.N) b0[e] = p.bias[nb0 + e];
+      if (PAIRED && nb1 + e < p.N) b1[e] = p.bias[nb1 + e];
     }
-    __syncthreads();
-    const int lpr = paired ? BN / 8 : BN / 4;   // lanes per row
-    const int rpi = 64 / lpr;                   // rows per wave-instruction
-    const int sub = lane / lpr, c = lane - sub * lpr;
-    // column operands of this lane are the same for every row
-    int n_out, nb0, nb1 = 0;                    // first output column, bias index (and second bias index for pairs)
-    const float* src_off;
-    if (paired) {
-      const int g = c >> 3, cc = (c & 7) * 4;   // 64-column packed group, offset inside its 32 outputs
-      nb0 = col_base + g * 64 + cc; nb1 = nb0 + 32;
-      n_out = ((col_base + g * 64) >> 1) + cc;
-      src_off = lds + g * 64 + cc;
-    } else {
-      nb0 = col_base + c * 4;
-      n_out = nb0;
-      src_off = lds + c * 4;
+  }
+  const bool use_res = EPI != EPI_ROPE && p.res && vec;
+  const bool use_rope = EPI == EPI_ROPE && vec && n_out < p.rope_cols;
+  auto fetch = [&](int m) -> f32x4 {            // the row operand of this lane: residual, or (cos, sin) rows of the rotary table
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (m < p.M) {
+      if (EPI == EPI_ROPE) { if (use_rope) v = *reinterpret_cast<const f32x4*>(p.rope + ((size_t)(m % p.rope_T) * 32 + ((n_out >> 1) & 31)) * 2); }
+      else if (use_res) v = *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + n_out);
     }
-    const int n_lim = paired ? (p.N >> 1) : p.N;
-    const bool col_ok = nb0 < p.N;
-    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
-    if (p.bias && col_ok) {
+    return v;
+  };
+  f32x4 pre[4][NIT];
+  auto prefetch = [&](int ps) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (nb0 + e < p.N) b0[e] = p.bias[nb0 + e];
-        if (paired && nb1 + e < p.N) b1[e] = p.bias[nb1 + e];
-      }
+    for (int it = 0; it < NIT; ++it) pre[ps][it] = fetch(row0 + ps * 16 + it * RPI + sub);
+  };
+  if (PREF) { prefetch(0); prefetch(1); prefetch(2); }
+  __syncthreads();                              // every wave has read its last fragments: the ring is free
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  const int nseq = p.row_len ? (p.M + p.seq_len - 1) / p.seq_len : 1;
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int mt = ps >> 1, hh = ps & 1;
+    // accumulator rows of this pass: register r = (2 hh + q) * 4 + e is tile row 16 hh + 8 q + 4 h + e
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lds[(8 * q + 4 * h + e) * RS + nt * 32 + j] = acc[mt][nt][(2 * hh + q) * 4 + e];
+    // row mask of the pass: its 16 rows lie in at most two sequences (seq_len >= 16 is checked on the host)
+    int t_first = 0, len_a = 0x7fffffff, len_b = 0x7fffffff, seq_len = 0x7fffffff;
+    if (p.row_len) {
+      const int mb = row0 + ps * 16, sb = min(mb / p.seq_len, nseq - 1);
+      t_first = mb - sb * p.seq_len; seq_len = p.seq_len;
+      len_a = p.row_len[sb]; len_b = p.row_len[min(sb + 1, nseq - 1)];
     }
-    // The residual may alias the output (in-place h += ...): a residual load placed next to its row's store stays behind the
-    // previous row's store, and its data then waits for that store's acknowledgement (vmcnt counts loads and stores in issue
-    // order) -- one HBM write round trip per row.  All residual rows of this wave and slab are requested first instead.
-    constexpr int MAXIT = SLAB / NW;
-    f32x4 rres[MAXIT];
-    const bool res_vec = p.res && vec_ok && col_ok && n_out + 3 < n_lim;
-#pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-      const int rr = wave * (SLAB / NW) + sub + it * rpi;
-      const int m = row_base + slab * SLAB + rr;
-      rres[it] = (res_vec && rr < (wave + 1) * (SLAB / NW) && m < p.M) ? *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + n_out)
-                                                                       : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-      const int rr = wave * (SLAB / NW) + sub + it * rpi;
-      if (rr >= (wave + 1) * (SLAB / NW)) continue;
-      const int m = row_base + slab * SLAB + rr;
-      if (m >= p.M || !col_ok) continue;
-      f32x4 v = *reinterpret_cast<const f32x4*>(src_off + rr * RS) + b0;
-      if (paired) {
-        const f32x4 lin = *reinterpret_cast<const f32x4*>(src_off + rr * RS + 32) + b1;
+    auto body = [&](const int rr, const f32x4 opnd) {
+      const int m = row0 + ps * 16 + rr;
+      if (m >= p.M || !col_ok) return;
+      f32x4 v = *reinterpret_cast<const f32x4*>(lds + rr * RS + lcol) + b0;
+      if (PAIRED) {
+        const f32x4 lin = *reinterpret_cast<const f32x4*>(lds + rr * RS + lcol + 32) + b1;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           v[e] = p.act == ACT_SWIGLU ? (v[e] * sigmoid_fast(v[e])) * lin[e] : tanh_fast(v[e]) * sigmoid_fast(lin[e]);
-      } else if (p.act != ACT_NONE) {
+      } else if (EPI == EPI_ACT) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act);
+        for (int e = 0; e < 4; ++e) v[e] = act_apply_fast(v[e], p.act);
       }
-      if (p.rope && n_out < p.rope_cols) {       // two (even, odd) pairs per lane
-        const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rope + ((size_t)(m % p.rope_T) * 32 + ((n_out >> 1) & 31)) * 2);
-        v = f32x4{v[0] * cs[0] - v[1] * cs[1], v[1] * cs[0] + v[0] * cs[1], v[2] * cs[2] - v[3] * cs[3], v[3] * cs[2] + v[2] * cs[3]};
-      }
+      if (EPI == EPI_ROPE && use_rope)           // two (even, odd) pairs per lane
+        v = f32x4{v[0] * opnd[0] - v[1] * opnd[1], v[1] * opnd[0] + v[0] * opnd[1], v[2] * opnd[2] - v[3] * opnd[3], v[3] * opnd[2] + v[2] * opnd[3]};
       v *= p.out_scale;
-      bool masked = false;
-      if (p.row_len) {
-        const int sb = m / p.seq_len;
-        masked = (m - sb * p.seq_len) >= p.row_len[sb];
-      }
-      float* dst = p.y + (size_t)m * p.ldy + n_out;
-      if (vec_ok && n_out + 3 < n_lim) {
-        if (p.res) v += rres[it];
+      const int t = t_first + rr;
+      const bool masked = t < seq_len ? t >= len_a : t - seq_len >= len_b;
+      if (vec) {
+        if (EPI != EPI_ROPE && use_res) v += opnd;
         if (masked) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.y) *reinterpret_cast<f32x4*>(dst) = v;
-        if (p.y_hi) {       // n_out % 4 == 0: the four columns share a 16-k chunk
-          typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-          bf16x4_t hi, lo;
-          split_bf16_x4(v, hi, lo);
-          const size_t o = plane_index(m, n_out, p.M);
-          *reinterpret_cast<bf16x4_t*>(p.y_hi + o) = hi;
-          *reinterpret_cast<bf16x4_t*>(p.y_lo + o) = lo;
-        }
-      } else {
+        if (p.y) *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + n_out) = v;
+        if (p.y_hi) *reinterpret_cast<f32x4*>(lds + rr * RS + ocol) = v;
+      } else {                                   // ragged / unaligned columns: element by element (no planes, no rotary)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (n_out + e < n_lim) {
             float o = v[e];
             if (p.res) o += p.res[(size_t)m * p.ldr + n_out + e];
-            if (p.y) dst[e] = masked ? 0.0f : o;
+            if (p.y) p.y[(size_t)m * p.ldy + n_out + e] = masked ? 0.0f : o;
           }
       }
+    };
+    if (PREF) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) body(it * RPI + sub, pre[ps][it]);
+    } else {
+#pragma unroll 1
+      for (int it = 0; it < NIT; ++it) body(it * RPI + sub, fetch(row0 + ps * 16 + it * RPI + sub));
     }
+    if (p.y_hi) {
+      // plane order: 16-byte unit u of a chunk's 512-byte run = (row u >> 1, columns 8 (u & 1) ..); a chunk's lanes write 128
+      // contiguous bytes per instruction
+      constexpr int CH = PAIRED ? 4 : 8;        // 16-column output chunks of this wave
+      constexpr int LPC = 64 / CH, NK = 32 / LPC;
+      const int chunk = lane / LPC;
+      const int n0 = (PAIRED ? (col0 >> 1) : col0) + chunk * 16;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int u = k * LPC + (lane % LPC);
+        const int rr = u >> 1, hf = u & 1;
+        const int m = row0 + ps * 16 + rr;
+        if (m >= p.M || n0 >= n_lim) continue;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(lds + rr * RS + chunk * 16 + hf * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(lds + rr * RS + chunk * 16 + hf * 8 + 4);
+        bf16x4_t h0, l0, h1, l1;
+        split_bf16_x4(v0, h0, l0);
+        split_bf16_x4(v1, h1, l1);
+        const size_t o = plane_index(m, n0 + hf * 8, p.M);
+        *reinterpret_cast<bf16x8_t*>(p.y_hi + o) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        *reinterpret_cast<bf16x8_t*>(p.y_lo + o) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    }
+    if (PREF && ps == 0) prefetch(3);
   }
 }
 
