@@ -184,7 +184,10 @@ def build_pipeline(args, world, rank, dev):
     # (CU-masked streams, hipExtStreamCreateWithCUMask, are accepted but have no effect for an unprivileged user on this pool.)
     from indextts_amd.serving import BatchPipeline
     lanes = max(1, args.decode_lanes)
-    pipe = None if args.no_overlap else BatchPipeline(tts, decode_lanes=lanes)
+    pipe = None if args.no_overlap else BatchPipeline(tts, decode_lanes=lanes, acoustic_workers=max(1, args.acoustic_workers),
+                                                      exclusive=args.turns)
+    if pipe is not None and args.trace_jobs:
+        pipe.trace = []
     pending = []
 
     def retire(fut):
@@ -257,6 +260,7 @@ def build_pipeline(args, world, rank, dev):
     step.flush = (lambda: None) if args.no_overlap else flush
     step.reference = lambda: tts.synthesize_batch(text, cond_dev, max_mel_tokens=M, noise=noise)[0]
     step.flushed = flushed
+    step.pipe = pipe
     return step, profiled, cpu_leg, stage_times, audio_s, desc
 
 
@@ -301,6 +305,12 @@ def main() -> int:
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--decode-lanes", type=int, default=3,
                     help="pipeline workload: decode chains of consecutive batches in flight at once (each on its own stream and host thread)")
+    ap.add_argument("--acoustic-workers", type=int, default=1, help="pipeline workload: s2mel + vocoder stages of different batches in flight at once")
+    ap.add_argument("--turns", action="store_true",
+                    help="pipeline workload: decode chains and acoustic stages take turns on the device instead of sharing it (measured equal)")
+    ap.add_argument("--s2mel-overlap", action="store_true",
+                    help="the CFM solver's two CFG halves on two streams (idxtts_s2mel_set_overlap): faster alone, slower beside decode lanes")
+    ap.add_argument("--trace-jobs", action="store_true", help="pipeline workload: log the host-side start / end of every decode and acoustic job")
     ap.add_argument("--no-overlap", action="store_true",
                     help="pipeline workload: run the K steps strictly one after the other (default: the decode chains of the next "
                          "--decode-lanes steps overlap the s2mel + vocoder stage of the current one)")
@@ -348,6 +358,7 @@ def main() -> int:
     from indextts_amd import _lib
     _lib.load()
     _lib.set_gemm_mode(0 if args.gemm == "f32" else 1)
+    _lib.set_s2mel_overlap(bool(args.s2mel_overlap))
     t0 = time.time()
     build = build_pipeline if args.workload == "pipeline" else build_vocoder
     step, profiled, cpu_leg, stage_times_fn, audio_s_per_step_per_gpu, desc = build(args, world, rank, dev)
@@ -382,6 +393,10 @@ def main() -> int:
         elapsed = float(tmax.item())
     assert torch.isfinite(out).all()
     log(f"[bench] rank {rank}: {args.steps} steps in {elapsed:.3f}s")
+    if getattr(getattr(step, "pipe", None), "trace", None):
+        for kind, a, b in sorted(step.pipe.trace, key=lambda r: r[1]):
+            if b >= t_start:
+                log(f"[bench] job {kind:8s} start {a - t_start:8.3f} s  end {b - t_start:8.3f} s  ({b - a:.3f} s)")
     equal_seq = None
     if hasattr(step, "reference"):      # every step has the same inputs: each retired batch must equal the sequential call bit for bit
         ref = step.reference()

@@ -622,4 +622,11 @@ int idxtts_set_gemm_mode(int mode) {
 
 int idxtts_get_gemm_mode(void) { return get_gemm_mode(); }
 
+int idxtts_s2mel_set_overlap(int on) {
+  set_s2mel_overlap(on);
+  return 0;
+}
+
+int idxtts_s2mel_get_overlap(void) { return get_s2mel_overlap(); }
+
 }  // extern "C"

@@ -51,7 +51,7 @@ int sample_greedy_forward(const SampleArgs& a, hipStream_t stream);
 // clamp_min(q, 1e-10), argmax; no penalty, no top-k / top-p.
 enum SampleMode { SAMPLE_HF = 1, SAMPLE_ACCEL = 2 };
 // The Exp(1) draw of element `idx` of a generation: the caller's tensor when it supplied one (reproduces torch's stream), else a
-// counter-based generator -- splitmix64 of (seed, idx) -> u in (0, 1] -> -log(u) -- so that default calls need no
+// counter-based generator -- splitmix64 of (seed, idx) -> u in (0, 1), 24 bits, never 0 or 1 -> -log(u) -- so that default calls need no
 // [steps][B][V] noise tensor (0.8 GB for 16 utterances x 1500 steps; 2.4 GB with 3 beams).
 __host__ __device__ static inline float exp1_draw(const float* noise, unsigned long long seed, size_t idx) {
   if (noise) return noise[idx];
@@ -59,7 +59,9 @@ __host__ __device__ static inline float exp1_draw(const float* noise, unsigned l
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   z = z ^ (z >> 31);
-  const float u = ((float)(z >> 40) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
+  // the open interval: u = 1 would make the draw 0 and probs / q infinite (or 0 / 0 for a filtered token) -- torch's exponential_
+  // never returns 0 either
+  const float u = ((float)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);
   return -logf(u);
 }
 struct SampleWarpArgs {

@@ -82,6 +82,18 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
   }
 }
 
+#ifdef V2_TIMING
+// Diagnostic build (tools/gemm_stamps.py; never the shipped library): s_memtime stamps of one wave per workgroup, written to a
+// buffer of their own: [workgroup][8] = start, first stage landed, end of the main loop, end of the epilogue, s_memrealtime x2.
+static unsigned long long* g_v2_stamps = nullptr;
+extern "C" int idxtts_dbg_v2_stamps(void* buf) { g_v2_stamps = static_cast<unsigned long long*>(buf); return 0; }
+#define V2_STAMP(k) do { if (q.stamps && tid == 64 * 5) q.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define V2_RSTAMP(k) do { if (q.stamps && tid == 64 * 5) q.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define V2_STAMP(k)
+#define V2_RSTAMP(k)
+#endif
+
 struct GemmV2P {
   GemmKP g;                      // shapes, epilogue operands, conv parameters (x unused)
   const __bf16* a_hi; const __bf16* a_lo;   // [K/16][a_rows][16]
@@ -89,6 +101,9 @@ struct GemmV2P {
   int a_rows, npad, nstages;
   int a_bytes, b_bytes;          // bytes of the hi + lo planes of each operand (buffer descriptors)
   int a_plane, b_plane;          // byte offset of the lo plane
+#ifdef V2_TIMING
+  unsigned long long* stamps;
+#endif
 };
 
 // Workgroup = 4 x 2 waves, each a 64 x 128 output tile (2 x 4 MFMA tiles): 256 x 256 per workgroup, 512 threads, 32 KiB stages,
@@ -144,6 +159,7 @@ __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, con
     const bool ok = a_m < p.M && t >= 0 && t < seq_n;
     return ok ? (seq_base + t) * 32 + dunit * 16 : (int)0x80000000;
   };
+  V2_STAMP(0); V2_RSTAMP(4);
   const int ns = q.nstages;
   const int sA = q.a_rows * 32, sB = q.npad * 32;          // bytes between two 16-k chunks of a plane
   const int cpt = TAPS ? (p.kc >> 4) : ns;                 // chunks per tap
@@ -249,6 +265,7 @@ __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, con
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
+  V2_STAMP(1);
   load_frags(f0, 0);
   int i = 0;
   // steady state, straight-line: two younger stages in flight behind every wait, a stage to request beside every compute
@@ -277,7 +294,13 @@ __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, con
     }
   }
   // (the last wait_stage left no DMA in flight; the epilogue synchronises the workgroup itself before it reuses the ring)
+  V2_STAMP(2);
   gemm_epilogue_wave<EPI>(p, acc, reinterpret_cast<float*>(smv2), bm * 256 + wm * 64, bn * 256 + wn * 128, wave, lane);
+  V2_STAMP(6);
+#ifdef V2_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  V2_STAMP(3); V2_RSTAMP(5);
 }
 
 // one output tile per workgroup; XCD x owns the row tiles == x (mod 8) (gemm.hip explains the two walk orders)
@@ -343,6 +366,9 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
   q.b_hi = static_cast<const __bf16*>(wplanes);
   q.b_lo = q.b_hi + (size_t)(w.K / 16) * q.npad * 16;
   q.nstages = w.K / 16;
+#ifdef V2_TIMING
+  q.stamps = g_v2_stamps;
+#endif
   const size_t b_plane = (size_t)(w.K / 16) * q.npad * 32;
   IDX_CHECK(2 * plane < (1ull << 31) && 2 * b_plane < (1ull << 31), "operand planes beyond the 2 GiB a buffer offset addresses");
   q.a_plane = (int)plane; q.a_bytes = (int)(2 * plane);

@@ -1,4 +1,5 @@
 #pragma once
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -31,7 +32,9 @@ struct GPTModel : ModelBase {
   const float *mel_emb = nullptr, *text_emb = nullptr, *mel_pos = nullptr, *text_pos = nullptr;
   int weight_fmt = WFMT_F32;      // storage format of the decode weight streams (quantize_weights)
   hipStream_t own_stream = nullptr;
-  int* oob_flag = nullptr;        // device int: set by the embedding gather when an index exceeds its table
+  static constexpr int OOB_SLOTS = 64;
+  int* oob_flag = nullptr;        // device ints (one per embed() call in flight): set by the embedding gather when an index exceeds its table
+  std::atomic<unsigned> oob_next{0};
   ~GPTModel() override {
     for (GraphSlot& g : graph_cache) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
     if (own_stream) (void)hipStreamDestroy(own_stream);

@@ -172,9 +172,9 @@ int GPTModel::finalize(std::map<std::string, HostTensor>& t, DeviceArena& arena)
   IDX_CHECK(d == cfg.heads * 64, "head_dim must be 64");
   IDX_CHECK(cfg.layers > 0 && (d & 15) == 0, "config");
   {
-    const int zero = 0;
+    const int zeros[OOB_SLOTS] = {0};
     void* flag = nullptr;
-    if (arena.upload_bytes(&zero, sizeof(int), &flag)) return 1;
+    if (arena.upload_bytes(zeros, sizeof(zeros), &flag)) return 1;
     oob_flag = static_cast<int*>(flag);
   }
   layers.resize(cfg.layers);
@@ -566,11 +566,14 @@ int GPTModel::embed(float* out, int rows, const int* text_ids, const int* text_p
   ga.table[4] = extra; ga.idx[4] = extra_idx;
   ga.table_rows[0] = cfg.number_text_tokens + 1; ga.table_rows[1] = cfg.text_pos_len;
   ga.table_rows[2] = cfg.number_mel_codes; ga.table_rows[3] = cfg.mel_pos_len;
-  ga.oob = oob_flag;
-  IDX_HIP(hipMemsetAsync(oob_flag, 0, sizeof(int), st));
+  // one flag slot per call in flight: embed() runs concurrently on several streams (serving.BatchPipeline's lanes), and a shared
+  // flag could be cleared by one call's memset before another call has read it
+  int* const flag = oob_flag + (oob_next.fetch_add(1, std::memory_order_relaxed) % OOB_SLOTS);
+  ga.oob = flag;
+  IDX_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
   if (gather_sum_rows(ga, rows, st)) return 1;
   int bad = 0;       // the reference's nn.Embedding raises IndexError on such an id (model_v2.py:759-760); fail as loudly
-  IDX_HIP(hipMemcpyAsync(&bad, oob_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  IDX_HIP(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, st));
   IDX_HIP(hipStreamSynchronize(st));
   static const char* names[] = {"", "text token id", "text position", "mel code", "mel position", "conditioning row"};
   if (bad) IDX_FAIL(std::string("embedding index out of range: ") + names[bad < 6 ? bad : 0]);

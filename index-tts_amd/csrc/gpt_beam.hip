@@ -73,6 +73,9 @@ int GPTModel::generate_beam(const float* inputs_embeds, const int* pad_left_host
   IDX_CHECK(B > 0 && R <= 64 && P > 0 && max_new > 0, "shape (B * num_beams <= 64)");
   IDX_CHECK(!beam->do_sample || (beam->temperature > 0.0f && beam->top_k >= 0 && beam->top_k <= 1024 && beam->top_p > 0.0f),
             "beam-sample needs a positive temperature, top_k <= 1024 and top_p > 0");
+  // the nucleus is cut inside the top-k survivors (beam_scores_kernel stages at most 2048 of them): without a top-k the whole
+  // vocabulary would survive and the threshold would come from whichever 2048 entries arrived first
+  IDX_CHECK(!beam->do_sample || beam->top_p >= 1.0f || (beam->top_k > 0 && beam->top_k <= 1024), "top-p needs 0 < top_k <= 1024");
   IDX_CHECK(beam->early_stopping == 0 || beam->early_stopping == 1, "early_stopping must be 0 (False) or 1 (True)");
   const int d = cfg.model_dim, V = cfg.number_mel_codes, S = P + 1;
   IDX_CHECK(max_new + 1 < cfg.mel_pos_len, "max_new_tokens exceeds the mel position table");

@@ -57,4 +57,8 @@ struct S2MelModel : ModelBase {
                    int Tg, float* cond_out, void* ws, size_t ws_bytes, hipStream_t st);
 };
 
+// the two CFG halves of the solver on two streams (s2mel.hip, dit_eval_halves); default on
+void set_s2mel_overlap(int on);
+int get_s2mel_overlap();
+
 }  // namespace idxtts

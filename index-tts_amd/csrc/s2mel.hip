@@ -18,6 +18,10 @@
 #include <cmath>
 #include <cstring>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "s2mel.h"
 
 namespace idxtts {
@@ -328,6 +332,27 @@ static CfmBuffers carve_cfm(const S2MelModel& m, void* ws, int B, int T, int n_s
 
 size_t S2MelModel::cfm_workspace_bytes(int B, int T, int n_steps) const { return carve_cfm(*this, nullptr, B, T, n_steps).bytes; }
 
+// The buffers of ONE half of the stacked [conditional | null] batch: every activation buffer is [2B*T rows][cols] (or planes
+// of that many rows), so half h is the block of B*T rows at h * B*T*cols elements -- for planes too: a half's hi + lo planes
+// [cols/16][B*T][16] are B*T*cols*4 bytes, laid out with rows = B*T.  The two halves never read each other's rows between
+// cfm_pack and the Euler update, which is what lets them run on two streams (dit_eval_halves).
+static CfmBuffers half_view(const S2MelModel& m, const CfmBuffers& w, int h, int B, int T) {
+  const auto& c = m.cfg;
+  const int D = c.hidden_dim, C = c.in_channels, Wh = c.wn_hidden, Win = 2 * C + D + c.style_dim;
+  const size_t R = (size_t)h * B * T;
+  CfmBuffers v = w;
+  auto sh = [&](float* p, int cols) { return p + R * cols; };
+  auto shp = [&](void* p, int cols) -> void* { return static_cast<float*>(p) + R * cols; };
+  v.x_in = sh(w.x_in, Win); v.ha = sh(w.ha, D); v.hb = sh(w.hb, D); v.hmid = sh(w.hmid, D); v.hn = sh(w.hn, D); v.qkv = sh(w.qkv, 3 * D);
+  v.att = sh(w.att, D); v.ff = sh(w.ff, m.ffn); v.xres = sh(w.xres, D); v.wn_x = sh(w.wn_x, Wh); v.wn_acts = sh(w.wn_acts, Wh);
+  v.wn_out = sh(w.wn_out, Wh); v.vout = sh(w.vout, C);
+  v.hn_p = shp(w.hn_p, std::max(D, Wh)); v.att_p = shp(w.att_p, D); v.ff_p = shp(w.ff_p, m.ffn); v.acts_p = shp(w.acts_p, Wh);
+  v.h_p = shp(w.h_p, D); v.wnx_p = shp(w.wnx_p, Wh); v.xres_p = shp(w.xres_p, D);
+  for (size_t i = 0; i < w.skips.size(); ++i) { v.skips[i] = sh(w.skips[i], D); v.skips_p[i] = shp(w.skips_p[i], D); }
+  v.lens2 = w.lens2 + h * B; v.lens2t = w.lens2t + h * B;
+  return v;
+}
+
 // xp / yp: split-bf16 planes of the input / output (GemmArgs::x_planes / y_planes); with xp the fp32 x is not read,
 // with yp and y == nullptr no fp32 output is written
 static int gemm(const LinearWeights& w, const float* x, int ldx, float* y, int ldy, int M, hipStream_t st, int act = ACT_NONE,
@@ -338,7 +363,8 @@ static int gemm(const LinearWeights& w, const float* x, int ldx, float* y, int l
   return gemm_forward(w, a, st);
 }
 
-static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipStream_t st) {
+// N2 sequences of T frames (one CFG half, or the stacked batch); lag_event (optional) is recorded behind the first attention
+static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipStream_t st, hipEvent_t lag_event) {
   const auto& c = m.cfg;
   const int D = c.hidden_dim, C = c.in_channels, Wh = c.wn_hidden, depth = c.depth, half = depth / 2;
   const int M = N2 * T, Win = 2 * C + D + c.style_dim;
@@ -387,6 +413,7 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
     return rows_norm_forward(n, st);
   };
   auto ada = [&](const float* x, const float* g, int mod_idx) { return ada_rows(x, g, mod_idx, M, chain); };
+  if (lag_event && depth < 2) IDX_HIP(hipEventRecord(lag_event, st));      // (a one-block model has no "behind the first attention")
   bool h_compact = false;      // h already holds only the tail rows (the last block produced it that way)
   if (gemm(m.merge, w.x_in, Win, w.ha, D, M, st)) return 1;
   float* h = w.ha;
@@ -443,6 +470,7 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
     }
     if (chain) { a.o = nullptr; a.o_planes = w.att_p; ap.o = nullptr; ap.o_planes = w.att_p; }
     if (qkv_planes ? flash_attn_planes_forward(ap, st) : flash_attn_forward(a, st)) return 1;
+    if (i == 0 && lag_event) IDX_HIP(hipEventRecord(lag_event, st));
     if (gemm(B.wo, w.att, D, w.hmid, D, M, st, ACT_NONE, h, D, chain ? w.att_p : nullptr)) return 1;           // h + attention(...)
     if (ada(w.hmid, B.ffn_g, 2 * i + 1)) return 1;
     if (gemm(B.w13, w.hn, D, chain ? nullptr : w.ff, m.ffn, M, st, ACT_SWIGLU, nullptr, 0, hn_p, chain ? w.ff_p : nullptr)) return 1;
@@ -515,6 +543,68 @@ static int dit_eval(S2MelModel& m, CfmBuffers& w, int N2, int T, int step, hipSt
   return gemm(m.conv2, w.att, Wh, w.vout, C, Mt, st);
 }
 
+// ---- the two CFG halves on two streams -------------------------------------------------------------------
+// Every kernel of the estimator alternates an MFMA-bound phase with an HBM-bound one (a GEMM tile: 57 k cycles of main loop, then
+// 22-39 k cycles in which all 256 CUs write their tiles at once at ~4.6 TB/s; in-kernel stamps, profiles/README.md "Round 3"), and
+// all workgroups of one launch are in the same phase.  Two launches of DIFFERENT kernels side by side are not: with the null
+// half of the batch a couple of kernels behind the conditional half, one half's epilogues drain while the other half multiplies
+// (tools/two_stream_gemm.py: the four GEMMs of a DiT layer 1290 -> 1098 us).  The halves share nothing between cfm_pack and the
+// Euler update; results are bit-identical to the single-stream order (same kernels on the same rows).
+struct HalfStreams { hipStream_t side = nullptr; hipEvent_t fork = nullptr, lag = nullptr, join = nullptr; };
+static std::map<std::pair<int, hipStream_t>, HalfStreams> g_half_streams;   // per (device, caller stream)
+static std::mutex g_half_mu;
+// Off by default: alone on the device the solver takes 9 % less time with it (542 -> 491 ms at configs[2]), a sequential
+// synthesize_batch 3 % less -- but in the serving pipeline the decode chains of the NEXT batches then run at less than half their
+// speed (two of three lanes 2.65 s instead of 1.18 s per 512 tokens, also when decode and acoustic stages take strict turns; not
+// understood: profiles/README.md "Round 3"), so the batch pipeline leaves it off.
+static int g_s2mel_overlap = 0;
+void set_s2mel_overlap(int on) { g_s2mel_overlap = on ? 1 : 0; }
+int get_s2mel_overlap() { return g_s2mel_overlap; }
+
+static int half_streams_for(hipStream_t st, HalfStreams* out) {
+  int dev = 0;
+  IDX_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_half_mu);
+  HalfStreams& hs = g_half_streams[std::make_pair(dev, st)];
+  if (!hs.side) {
+    // same priority as the caller's stream: the halves are peers (a side stream of HIGHER priority than its caller starves the
+    // caller's half -- measured: the solver took twice as long on a low-priority serving stream)
+    int prio = 0;
+    if (st) IDX_HIP(hipStreamGetPriority(st, &prio));
+    IDX_HIP(hipStreamCreateWithPriority(&hs.side, hipStreamNonBlocking, prio));
+    IDX_HIP(hipEventCreateWithFlags(&hs.fork, hipEventDisableTiming));
+    IDX_HIP(hipEventCreateWithFlags(&hs.lag, hipEventDisableTiming));
+    IDX_HIP(hipEventCreateWithFlags(&hs.join, hipEventDisableTiming));
+  }
+  *out = hs;
+  return 0;
+}
+
+// both halves of one estimator evaluation; `halves` = 2 (the solver) or 1 (the stand-alone entry point: conditional half only)
+static int dit_eval_halves(S2MelModel& m, CfmBuffers& w, int B, int T, int step, int halves, hipStream_t st) {
+  CfmBuffers v0 = half_view(m, w, 0, B, T);
+  if (halves == 1) return dit_eval(m, v0, B, T, step, st, nullptr);
+  CfmBuffers v1 = half_view(m, w, 1, B, T);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cap);
+  if (!g_s2mel_overlap || prof_enabled() || cap != hipStreamCaptureStatusNone) {     // per-launch event timing wants kernels alone
+    if (dit_eval(m, v0, B, T, step, st, nullptr)) return 1;
+    return dit_eval(m, v1, B, T, step, st, nullptr);
+  }
+  HalfStreams hs;
+  if (half_streams_for(st, &hs)) return 1;
+  IDX_HIP(hipEventRecord(hs.fork, st));
+  IDX_HIP(hipStreamWaitEvent(hs.side, hs.fork, 0));
+  // the null half starts when the conditional half has finished its first attention (a few kernels in): from then on the two
+  // chains stay that far apart
+  if (dit_eval(m, v0, B, T, step, st, hs.lag)) return 1;
+  IDX_HIP(hipStreamWaitEvent(hs.side, hs.lag, 0));
+  if (dit_eval(m, v1, B, T, step, hs.side, nullptr)) return 1;
+  IDX_HIP(hipEventRecord(hs.join, hs.side));
+  IDX_HIP(hipStreamWaitEvent(st, hs.join, 0));
+  return 0;
+}
+
 int S2MelModel::cfm(const float* mu, const int* x_lens_host, const float* prompt, const int* prompt_lens_host, int Tp_max,
                     const float* style, const float* z, const float* t_emb, const float* dt_host, int n_steps, float cfg_rate,
                     float* out, int B, int T, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -558,9 +648,9 @@ int S2MelModel::cfm(const float* mu, const int* x_lens_host, const float* prompt
     pk.cond = w.condp; pk.cond_null = cond_proj.bias; pk.style = style;
     pk.B = B; pk.T = T; pk.C = C; pk.D = D; pk.S = cfg.style_dim; pk.Tp_max = Tp_max;
     if (cfm_pack(pk, st)) return 1;
-    if (dit_eval(*this, w, 2 * B, T, s, st)) return 1;
+    if (dit_eval_halves(*this, w, B, T, s, 2, st)) return 1;
     CfmEulerArgs eu;
-    eu.x = w.xstate; eu.v = w.vout; eu.ldv = C; eu.prompt_len = w.plen; eu.B = B; eu.T = T; eu.C = C; eu.dt = dt_host[s]; eu.cfg_rate = cfg_rate;
+    eu.x = w.xstate; eu.v = w.vout; eu.v_null = w.vout + (size_t)B * T * C; eu.ldv = C; eu.prompt_len = w.plen; eu.B = B; eu.T = T; eu.C = C; eu.dt = dt_host[s]; eu.cfg_rate = cfg_rate;
     eu.v_t0 = w.tail_t0; eu.v_T = T - w.tail_t0;
     if (cfm_euler(eu, st)) return 1;
   }
@@ -599,7 +689,7 @@ int S2MelModel::estimator(const float* x, const float* prompt, const int* prompt
   pk.cond = w.condp; pk.cond_null = cond_proj.bias; pk.style = style;
   pk.B = B; pk.T = T; pk.C = C; pk.D = D; pk.S = cfg.style_dim; pk.Tp_max = Tp_max;
   if (cfm_pack(pk, st)) return 1;
-  if (dit_eval(*this, w, 2 * B, T, 0, st)) return 1;
+  if (dit_eval_halves(*this, w, B, T, 0, 1, st)) return 1;
   IDX_HIP(hipMemcpyAsync(out_tm, w.vout, (size_t)B * T * C * sizeof(float), hipMemcpyDeviceToDevice, st));
   return 0;
 }

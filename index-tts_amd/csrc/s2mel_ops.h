@@ -21,7 +21,8 @@ int cfm_pack(const CfmPackArgs& a, hipStream_t st);
 
 struct CfmEulerArgs {    // x += dt*((1+cfg)*v_cond - cfg*v_null); x[:, :, :Tp] = 0   (flow_matching.py:104-113)
   float* x;                      // [B][C][T]
-  const float* v; int ldv;       // [2B*T][C] DiT output rows
+  const float* v; int ldv;       // conditional half: [B*T][C] DiT output rows
+  const float* v_null = nullptr; // null half (default: the B*v_T rows behind the conditional half)
   const int* prompt_len;
   int B, T, C;
   float dt, cfg_rate;

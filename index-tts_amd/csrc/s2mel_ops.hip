@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void cfm_euler_kernel(const CfmEulerArgs p) {
   if (t < p.prompt_len[b] || t < p.v_t0) { p.x[idx] = 0.0f; return; }
   const int vT = p.v_T > 0 ? p.v_T : p.T, tv = t - p.v_t0;
   const float vc = p.v[((size_t)b * vT + tv) * p.ldv + c];
-  const float vn = p.v[((size_t)(p.B + b) * vT + tv) * p.ldv + c];
+  const float vn = p.v_null ? p.v_null[((size_t)b * vT + tv) * p.ldv + c] : p.v[((size_t)(p.B + b) * vT + tv) * p.ldv + c];
   const float dphi = (1.0f + p.cfg_rate) * vc - p.cfg_rate * vn;
   p.x[idx] = p.x[idx] + p.dt * dphi;
 }

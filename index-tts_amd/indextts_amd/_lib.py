@@ -24,7 +24,7 @@ SYMBOLS = [
     "idxtts_gpt_create", "idxtts_gpt_quantize_weights", "idxtts_gpt_workspace_bytes", "idxtts_gpt_embed", "idxtts_gpt_generate", "idxtts_gpt_generate_sampled", "idxtts_gpt_latent",
     "idxtts_gpt_beam_workspace_bytes", "idxtts_gpt_generate_beam",
     "idxtts_s2mel_create", "idxtts_s2mel_cond_workspace_bytes", "idxtts_s2mel_prepare_cond",
-    "idxtts_s2mel_cfm_workspace_bytes", "idxtts_s2mel_cfm", "idxtts_set_gemm_mode", "idxtts_get_gemm_mode",
+    "idxtts_s2mel_cfm_workspace_bytes", "idxtts_s2mel_cfm", "idxtts_set_gemm_mode", "idxtts_get_gemm_mode", "idxtts_s2mel_set_overlap", "idxtts_s2mel_get_overlap",
     "idxtts_s2mel_estimator", "idxtts_s2mel_regulate", "idxtts_cond_create", "idxtts_cond_workspace_bytes", "idxtts_cond_forward", "idxtts_emovec_merge",
     "idxtts_gpt_graph_cache_entries", "idxtts_w2vbert_create", "idxtts_w2vbert_workspace_bytes", "idxtts_w2vbert_forward",
     "idxtts_repcodec_create", "idxtts_repcodec_workspace_bytes", "idxtts_repcodec_quantize",
@@ -270,6 +270,34 @@ def profile_read() -> dict:
 GEMM_F32, GEMM_BF16X3 = 0, 1
 
 
+class StreamWorkspaces:
+    """Grow-only device workspaces, one per HIP stream: calls on one stream are ordered and may share a buffer, calls on different
+    streams (several host threads, serving.BatchPipeline) may not.  Least-recently-used streams beyond `max_entries` are dropped."""
+
+    def __init__(self, max_entries: int = 8):
+        import collections
+        import threading
+        self.max_entries = max_entries
+        self._ws = collections.OrderedDict()
+        self._lock = threading.Lock()
+
+    def get(self, need: int, device):
+        import torch
+        if need <= 0:
+            raise RuntimeError("workspace query returned 0")
+        device = torch.device(device)
+        key = (device.index, int(torch.cuda.current_stream(device).cuda_stream))
+        with self._lock:
+            ws = self._ws.pop(key, None)
+            if ws is None or ws.numel() < need:
+                ws = None
+                ws = torch.empty(need, dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+            while len(self._ws) > self.max_entries:
+                self._ws.popitem(last=False)
+        return ws
+
+
 def set_gemm_mode(mode: int) -> None:
     """0 = exact fp32 MFMA everywhere; 1 (library default) = split-bf16 for the GEMM-shaped passes with M >= 256."""
     check(load().idxtts_set_gemm_mode(int(mode)))
@@ -277,3 +305,12 @@ def set_gemm_mode(mode: int) -> None:
 
 def get_gemm_mode() -> int:
     return int(load().idxtts_get_gemm_mode())
+
+
+def set_s2mel_overlap(on: bool) -> None:
+    """The CFM solver's two CFG halves on two streams (default) or one after the other on the caller's stream."""
+    check(load().idxtts_s2mel_set_overlap(int(bool(on))))
+
+
+def get_s2mel_overlap() -> bool:
+    return bool(load().idxtts_s2mel_get_overlap())

@@ -1,11 +1,12 @@
 """Host-side mirror of `indextts.infer_v2.IndexTTS2` for the hot path (reference infer_v2.py:69-937).
 
-Scope: the three hot stages -- GPT decode + latent pass, s2mel, BigVGAN -- the GPT's own prompt
-conditioning (conformer + perceiver + emotion vector, model_v2.py:627-671, 897-910; hoisted out of the segment loop) and the
-segment loop that sequences them (infer_v2.py:732-881), with the reference's return contract (905-937) and generation
-defaults (714-722: beam-sample, num_beams=3).  The audio-side prompt encoders (w2v-bert, RepCodec, CAMPPlus, mel; infer_v2.py:
-618-696) and the text front-end are "next" rows (§8f): their OUTPUTS enter here as prompt features (`PromptFeatures`) or a ready
-`PromptConditioning` bundle, and token ids.
+Scope: the three hot stages -- GPT decode + latent pass, s2mel, BigVGAN --, the GPT's own prompt conditioning
+(conformer + perceiver + emotion vector, model_v2.py:627-671, 897-910; hoisted out of the segment loop), the audio-side prompt
+encoders (w2v-bert, RepCodec, CAMPPlus, mel; infer_v2.py:618-696 -> indextts_amd/prompt.py), the text front-end (tokenizer.py,
+segmenter.py) and the segment loop that sequences them (infer_v2.py:732-881), with the reference's return contract (905-937) and
+generation defaults (714-722: beam-sample, num_beams=3).  `IndexTTS2(cfg_path, model_dir)` assembles all of it from a
+checkpoint directory as the reference's constructor does; `infer()` takes a WAV path + a string, or any of the intermediate
+forms (`PromptAudio`, `PromptFeatures`, `PromptConditioning`; token-id segments).
 """
 from __future__ import annotations
 
@@ -115,13 +116,16 @@ class PromptConditioning:
 class IndexTTS2:
     """Drop-in for the hot path of `indextts.infer_v2.IndexTTS2`.
 
-    Construct from state dicts (reference key layout) with `from_state_dicts`, or from a checkpoint directory
-    with the reference's constructor signature (infer_v2.py:69-72) when `gpt.pth`, `s2mel.pth` and the BigVGAN
-    generator are present there (they are not shipped offline).
+    Construct from a checkpoint directory with the reference's constructor signature (infer_v2.py:69-72): everything that
+    constructor loads (infer_v2.py:138-289) is assembled -- gpt / s2mel / BigVGAN, the semantic model + its statistics, the
+    semantic codec, CAMPPlus, the emotion banks, the tokenizer -- so `infer("voice.wav", "text", "out.wav")` works as it does there
+    (files are looked up where the reference looks, hub cache included; nothing is downloaded).  Or from state dicts
+    (reference key layout) with `from_state_dicts` (+ `attach_prompt_models`).
     """
 
     def __init__(self, cfg_path="checkpoints/config.yaml", model_dir="checkpoints", use_fp16=False, device=None,
-                 use_cuda_kernel=None, use_deepspeed=False, use_accel=False, use_torch_compile=False, gpt_weight_format=None):
+                 use_cuda_kernel=None, use_deepspeed=False, use_accel=False, use_torch_compile=False, gpt_weight_format=None,
+                 segment_batch: int = 16):
         # use_fp16 (reference: gpt.half() + fp16 autocast, infer_v2.py:109, 145-146) maps to bf16 STORAGE of the GPT weights:
         # the arithmetic of the HIP path stays fp32.  gpt_weight_format ("f32" | "bf16" | "fp8") overrides it.
         if gpt_weight_format is None:
@@ -131,20 +135,39 @@ class IndexTTS2:
         if missing:
             raise FileNotFoundError(f"IndexTTS-2 checkpoints not found ({missing}); use IndexTTS2.from_state_dicts(...)")
         from .checkpoint import config_from_yaml, load_reference_checkpoints
-        cfg, raw = config_from_yaml(cfg_path) if os.path.exists(cfg_path) else (PipelineConfig(), None)
+        cfg, raw = config_from_yaml(cfg_path, model_dir) if os.path.exists(cfg_path) else (PipelineConfig(), None)
         gpt_sd, s2mel_sd, voc_sd = load_reference_checkpoints(model_dir, raw)
-        self._init(cfg, gpt_sd, s2mel_sd, voc_sd, device, gpt_weight_format)
+        self._init(cfg, gpt_sd, s2mel_sd, voc_sd, device, gpt_weight_format, segment_batch=segment_batch)
+        # the rest of the reference's constructor (infer_v2.py:187-289): semantic model + statistics, semantic codec, CAMPPlus,
+        # emotion banks, tokenizer
+        from .checkpoint import load_prompt_checkpoints, reference_text_normalizer
+        self.model_dir = model_dir
+        self.attach_prompt_models(load_prompt_checkpoints(model_dir, raw), normalizer=reference_text_normalizer())
+
+    def attach_prompt_models(self, ck: dict, normalizer=None) -> None:
+        """ck: checkpoint.load_prompt_checkpoints()'s dict (state dicts in the reference modules' own key layouts, statistics,
+        emotion banks, bpe path) -> self.prompt_encoders, the emotion banks, self.tokenizer."""
+        from .prompt import PromptEncoders
+        from .tokenizer import TextTokenizer
+        self.prompt_encoders = PromptEncoders(ck["w2vbert"], ck["codec"], ck["campplus"], self.s2mel, device=self.device,
+                                              w2vbert_cfg=ck["w2vbert_cfg"], codec_cfg=ck["codec_cfg"], campplus_cfg=ck["campplus_cfg"],
+                                              semantic_mean=ck["semantic_mean"], semantic_std=ck["semantic_std"], mel_kwargs=ck.get("mel_kwargs"))
+        self.set_emotion_matrices(ck["emo_matrix"], ck["spk_matrix"], ck["emo_num"])
+        self.normalizer = normalizer
+        self.tokenizer = TextTokenizer(ck["bpe_path"], normalizer)
+        self.bpe_path = ck["bpe_path"]
 
     @classmethod
     def from_state_dicts(cls, cfg: PipelineConfig, gpt_sd, s2mel_sd, bigvgan_sd, device=None, gpt_weight_format="f32",
-                         keep_effective_gpt=False) -> "IndexTTS2":
+                         keep_effective_gpt=False, segment_batch: int = 16) -> "IndexTTS2":
         """gpt_weight_format: "f32" | "bf16" | "fp8" storage of the GPT linear weights (UnifiedVoice); keep_effective_gpt keeps
-        `self.gpt.effective_state_dict` (the rounded model, reference keys) for parity checks."""
+        `self.gpt.effective_state_dict` (the rounded model, reference keys) for parity checks; segment_batch: segments of one
+        infer() call synthesised together (1 = the reference's loop as written)."""
         self = cls.__new__(cls)
-        self._init(cfg, gpt_sd, s2mel_sd, bigvgan_sd, device, gpt_weight_format, keep_effective_gpt)
+        self._init(cfg, gpt_sd, s2mel_sd, bigvgan_sd, device, gpt_weight_format, keep_effective_gpt, segment_batch)
         return self
 
-    def _init(self, cfg, gpt_sd, s2mel_sd, bigvgan_sd, device, gpt_weight_format="f32", keep_effective_gpt=False):
+    def _init(self, cfg, gpt_sd, s2mel_sd, bigvgan_sd, device, gpt_weight_format="f32", keep_effective_gpt=False, segment_batch=16):
         if device is None:
             device = f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cpu"
         self.device = torch.device(device)
@@ -160,7 +183,7 @@ class IndexTTS2:
         self._diffusion_steps = int(os.environ.get("TARS_DIFFUSION_STEPS", cfg.diffusion_steps))   # infer_v2.py:125
         self._cfg_rate = float(os.environ.get("TARS_CFG_RATE", cfg.cfg_rate))                      # infer_v2.py:126
         self.last_stage_times = {}
-        self.segment_batch = int(os.environ.get("IDXTTS_SEGMENT_BATCH", 16))      # segments of one infer() call synthesised together
+        self.segment_batch = int(segment_batch)      # segments of one infer() call synthesised together
 
     # ------------------------------------------------------------------------------------------
     def synthesize_batch(self, text_tokens: torch.Tensor, cond: PromptConditioning, max_mel_tokens: int = 1500,
@@ -276,8 +299,9 @@ class IndexTTS2:
               return_numpy=False, **generation_kwargs):
         """Reference signature and return contract (infer_v2.py:541-567): the generator itself when `stream_return`, else its
         first (only) item -- the output path, an InferenceResult, or (sampling_rate, int16 [n, 1]) -- or None for empty input.
-        On this path `spk_audio_prompt` must be a PromptConditioning and `text` a list of token-id segments
-        (List[List[int]]) or one segment (List[int] / 1-D tensor)."""
+        `spk_audio_prompt` (and `emo_audio_prompt`): a WAV file path as in the reference, or a PromptAudio / PromptFeatures /
+        PromptConditioning; `text`: a string (needs self.tokenizer), a list of token-id segments (List[List[int]]) or one segment
+        (List[int] / 1-D tensor)."""
         gen = self.infer_generator(spk_audio_prompt, text, output_path, emo_audio_prompt, emo_alpha, emo_vector, use_emo_text,
                                    emo_text, use_random, interval_silence, verbose, max_text_tokens_per_segment, stream_return,
                                    more_segment_before, return_audio=return_audio, return_numpy=return_numpy, **generation_kwargs)

@@ -71,15 +71,10 @@ class S2Mel:
             sd = dict(state_dict)
             sd["rope_cache"] = rope_cache(min(max_frames, cfg.block_size), cfg.head_dim, cfg.rope_base)
             _lib.load_state_dict(h, sd)
-        self._ws = None
+        self._ws = _lib.StreamWorkspaces()
 
     def _workspace(self, need: int) -> torch.Tensor:
-        if need == 0:
-            raise RuntimeError("workspace query returned 0")
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        return self._ws.get(need, self.device)       # one per stream: several acoustic stages may run at once (serving.py)
 
     # ------------------------------------------------------------------------------------------
     def prepare_condition(self, latent: torch.Tensor, codes: torch.Tensor, code_lens) -> tuple:

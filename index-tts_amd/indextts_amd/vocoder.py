@@ -137,7 +137,7 @@ class BigVGAN:
         sd.setdefault("activation_post.upsample.filter", f.reshape(1, 1, 12))
         sd.setdefault("activation_post.downsample.lowpass.filter", f.reshape(1, 1, 12))
         _lib.load_state_dict(h, sd)
-        self._ws = None
+        self._wss = _lib.StreamWorkspaces()
 
     def workspace_bytes(self, B: int, Tm: int) -> int:
         return int(_lib.load().idxtts_bigvgan_workspace_bytes(self._h, B, Tm))
@@ -154,9 +154,7 @@ class BigVGAN:
         wav = torch.empty(B, 1, Tm * self.cfg.total_upsample, device=mel.device, dtype=torch.float32)
         if B == 0 or Tm == 0:
             return wav
-        need = self.workspace_bytes(B, Tm)
-        if self._ws is None or self._ws.numel() < need or self._ws.device != mel.device:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=mel.device)
+        ws = self._wss.get(self.workspace_bytes(B, Tm), mel.device)     # one per stream
         if lengths is not None:
             if stage:
                 raise ValueError("stage output is not available for ragged batches")
@@ -165,8 +163,8 @@ class BigVGAN:
                 raise ValueError("lengths must be [B] with 0 <= lengths[b] <= Tm")
             lens_d = lens.to(mel.device)
             mel = (mel * (torch.arange(Tm, device=mel.device)[None, None, :] < lens_d[:, None, None])).contiguous()
-            _lib.check(lib.idxtts_bigvgan_fwd_ragged(self._h, _lib.ptr(mel), _lib.ptr(lens_d), _lib.ptr(wav), B, Tm, _lib.ptr(self._ws),
-                                                     self._ws.numel(), int(clamp), _lib.current_stream()))
+            _lib.check(lib.idxtts_bigvgan_fwd_ragged(self._h, _lib.ptr(mel), _lib.ptr(lens_d), _lib.ptr(wav), B, Tm, _lib.ptr(ws),
+                                                     ws.numel(), int(clamp), _lib.current_stream()))
             return wav
         stage_out = None
         if stage:
@@ -174,8 +172,8 @@ class BigVGAN:
             for u in self.cfg.upsample_rates[:stage]:
                 T *= u
             stage_out = torch.empty(B, self.cfg.channels(stage), T, device=mel.device, dtype=torch.float32)
-        _lib.check(lib.idxtts_bigvgan_fwd(self._h, _lib.ptr(mel), _lib.ptr(wav), B, Tm, _lib.ptr(self._ws),
-                                          self._ws.numel(), int(clamp), int(stage), _lib.ptr(stage_out),
+        _lib.check(lib.idxtts_bigvgan_fwd(self._h, _lib.ptr(mel), _lib.ptr(wav), B, Tm, _lib.ptr(ws),
+                                          ws.numel(), int(clamp), int(stage), _lib.ptr(stage_out),
                                           _lib.current_stream()))
         return (wav, stage_out) if stage else wav
 

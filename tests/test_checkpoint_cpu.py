@@ -96,3 +96,43 @@ def test_config_from_reference_yaml(tmp_path):
     ref["gpt"]["layers"] = 12
     path.write_text(yaml.safe_dump(ref))
     assert config_from_yaml(str(path))[0].gpt.layers == 12
+
+
+def test_prompt_side_checkpoints_round_trip(tmp_path):
+    """Everything else the reference's constructor loads (infer_v2.py:187-289: w2v-bert snapshot + statistics, semantic codec,
+    CAMPPlus, emotion banks, bpe.model), written by tests/ckpt_dir.py in the reference's layouts, comes back as the state dicts the
+    HIP contexts consume -- and the dimensions come back from config.yaml / the snapshots' config.json."""
+    from ckpt_dir import EMO_NUM, write_checkpoint_dir
+    from indextts_amd.checkpoint import config_from_yaml, load_prompt_checkpoints
+    S = write_checkpoint_dir(tmp_path)
+    cfg, raw = config_from_yaml(str(tmp_path / "config.yaml"), str(tmp_path))
+    assert cfg == S["cfg"], "config.yaml (+ BigVGAN config.json) must reproduce the pipeline configuration"
+    gpt, s2mel, voc = load_reference_checkpoints(str(tmp_path), raw)
+    for got, want, name in ((gpt, S["gpt"], "gpt"), (s2mel, S["s2mel"], "s2mel"), (voc, S["voc"], "bigvgan")):
+        assert set(got) == set(want), (name, sorted(set(got) ^ set(want))[:5])
+        for k in want:
+            np.testing.assert_allclose(got[k].numpy(), np.asarray(want[k]), rtol=2e-6, atol=1e-7, err_msg=f"{name}:{k}")
+    ck = load_prompt_checkpoints(str(tmp_path), raw)
+    assert ck["w2vbert_cfg"] == S["wcfg"] and ck["codec_cfg"] == S["ccfg"] and ck["campplus_cfg"] == S["pcfg"]
+    w2v = dict(S["w2v"])
+    mean, std = w2v.pop("semantic_mean"), w2v.pop("semantic_std")
+    np.testing.assert_array_equal(ck["semantic_mean"].numpy(), mean)
+    np.testing.assert_allclose(ck["semantic_std"].numpy(), std, rtol=2e-7)        # stored as the variance, as the reference's file does
+    for got, want, name in ((ck["w2vbert"], w2v, "w2vbert"), (ck["codec"], S["codec"], "codec"), (ck["campplus"], S["campplus"], "campplus")):
+        assert set(got) == set(want), (name, sorted(set(got) ^ set(want))[:5])
+        for k in want:
+            np.testing.assert_array_equal(got[k].numpy(), np.asarray(want[k]), err_msg=f"{name}:{k}")
+    np.testing.assert_array_equal(ck["emo_matrix"].numpy(), S["banks"]["emo_matrix"])
+    np.testing.assert_array_equal(ck["spk_matrix"].numpy(), S["banks"]["spk_matrix"])
+    assert ck["emo_num"] == EMO_NUM and os.path.exists(ck["bpe_path"]) and ck["mel_kwargs"]["num_mels"] == cfg.s2mel.in_channels
+    assert ck["mel_kwargs"]["fmax"] is None
+
+
+def test_missing_prompt_side_file_is_reported(tmp_path):
+    import pytest
+    from ckpt_dir import write_checkpoint_dir
+    from indextts_amd.checkpoint import load_prompt_checkpoints
+    write_checkpoint_dir(tmp_path)
+    os.remove(tmp_path / "feat1.pt")
+    with pytest.raises(FileNotFoundError):
+        load_prompt_checkpoints(str(tmp_path), {"spk_matrix": "feat1.pt"})

@@ -86,6 +86,20 @@ def test_beam_search_vs_reference(ref, device, tag, mode, graph):
     np.testing.assert_array_equal(codes.cpu().numpy(), want)
 
 
+def test_beam_sample_top_p_without_top_k_is_refused(ref, device):
+    """The nucleus cut works on the top-k survivors (at most 2048 staged on the chip): top_p < 1 with top_k off would leave the
+    whole vocabulary alive and cut it at an arbitrary subset -- refused loudly, as the num_beams = 1 sampler refuses it."""
+    g, cfg, w, uv = ref
+    with pytest.raises(RuntimeError, match="top-p needs 0 < top_k"):
+        uv.inference_speech(torch.from_numpy(g["cond_latent"]), torch.from_numpy(g["text"]), emo_vec=torch.from_numpy(g["emovec_merged"]),
+                            max_generate_length=4, do_sample=True, num_beams=3, top_p=0.8, top_k=0, temperature=0.8,
+                            repetition_penalty=10.0, length_penalty=0.0)
+    # top_p = 1 with top_k off is the plain softmax: allowed
+    uv.inference_speech(torch.from_numpy(g["cond_latent"]), torch.from_numpy(g["text"]), emo_vec=torch.from_numpy(g["emovec_merged"]),
+                        max_generate_length=4, do_sample=True, num_beams=3, top_p=1.0, top_k=0, temperature=0.8,
+                        repetition_penalty=10.0, length_penalty=0.0)
+
+
 def test_inference_speech_from_prompt_features_vs_reference(golden_dir, device):
     """inference_speech fed the raw prompt features, as the reference's call site does (infer_v2.py:760-775): conditioning encoders
     + emotion vector + greedy decode in one call, equal to the reference's greedy codes."""

@@ -1,32 +1,79 @@
-import ctypes, os, sys
+#!/usr/bin/env python3
+"""Do two DIFFERENT GEMMs of half the rows each, on two streams, finish sooner than the same two GEMMs at full M one after the
+other?  (Phase diversity between the store-bound epilogues of one kernel and the MFMA-bound loops of the other.)"""
+import ctypes
+import os
+import sys
 from ctypes import c_void_p
-sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "index-tts_amd"))
-import torch
-from indextts_amd import _lib
-lib = _lib.load(); dev = torch.device("cuda:0")
-def mk(M, N, K):
-    w = (torch.rand(N, K) - 0.5).contiguous(); x = (torch.rand(M, K, device=dev) - 0.5).contiguous(); y = torch.empty(M, N, device=dev)
-    h = c_void_p(); _lib.check(lib.idxtts_linear_create(_lib.ptr(w), None, N, K, 0, ctypes.byref(h))); return h, x, y
-def run(h, x, y, M, N, K, st):
-    _lib.check(lib.idxtts_linear_fwd(h, _lib.ptr(x), K, _lib.ptr(y), N, None, 0, M, 0, 1, c_void_p(st.cuda_stream)))
-for (N, K) in [(1536, 512), (512, 512), (3072, 512), (1024, 2560)]:
-    M = 50208
-    A = mk(M, N, K); B1 = mk(M // 2, N, K); B2 = mk(M // 2, N, K)
-    s0, s1, s2 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
-    for _ in range(3):
-        run(*A, M, N, K, s0); run(*B1, M // 2, N, K, s1); run(*B2, M // 2, N, K, s2)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "index-tts_amd"))
+import torch  # noqa: E402
+from indextts_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+dev = torch.device("cuda:0")
+
+
+def mk(M, N, K, act=0):
+    w = (torch.rand(N, K) - 0.5).contiguous()
+    h = c_void_p()
+    _lib.check(lib.idxtts_linear_create(_lib.ptr(w), None, N, K, 0, ctypes.byref(h)))
+    x = (torch.rand(M, K, device=dev) - 0.5)
+    y = torch.empty(M, N // 2 if act == 3 else N, device=dev)
+    return h, x, y, (M, N, K, act)
+
+
+def fwd(g, M, stream, row0=0):
+    h, x, y, (_, N, K, act) = g
+    n_out = y.shape[1]
+    _lib.check(lib.idxtts_linear_fwd(h, c_void_p(x.data_ptr() + row0 * K * 4), K, c_void_p(y.data_ptr() + row0 * n_out * 4), n_out, None, 0, M, act, 1,
+                                     c_void_p(stream.cuda_stream)))
+
+
+def timeit(fn, iters=10):
+    for _ in range(2):
+        fn()
     torch.cuda.synchronize()
-    it = 20
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(s0)
-    for _ in range(it): run(*A, M, N, K, s0)
-    e1.record(s0); torch.cuda.synchronize(); t_one = e0.elapsed_time(e1) / it
-    import time
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(it):
-        run(*B1, M // 2, N, K, s1); run(*B2, M // 2, N, K, s2)
-    torch.cuda.synchronize(); t_two = (time.perf_counter() - t) * 1e3 / it
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(it): run(*A, M, N, K, s0)
-    torch.cuda.synchronize(); t_one_wall = (time.perf_counter() - t) * 1e3 / it
-    print(f"N={N} K={K}: one GEMM M={M}: {t_one:.3f} ms (wall {t_one_wall:.3f});  two halves on two streams: {t_two:.3f} ms", flush=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+if __name__ == "__main__":
+    M = 50208
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    chains = {
+        "dit layer (qkv, wo, w13, w2)": [(1536, 512, 0), (512, 512, 0), (3072, 512, 3), (512, 1536, 0)],
+        "qkv + w2": [(1536, 512, 0), (512, 1536, 0)],
+    }
+    for name, ops in chains.items():
+        gs = [mk(M, N, K, act) for (N, K, act) in ops]
+
+        def seq():
+            for g in gs:
+                fwd(g, M, main)
+
+        def two(offset):
+            # stream 0 walks the chain on rows [0, M/2), stream 1 on the other half, `offset` ops behind (wrapping around)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            s0.wait_event(ev); s1.wait_event(ev)
+            n = len(gs)
+            for i in range(n):
+                fwd(gs[i], M // 2, s0, 0)
+                fwd(gs[(i + offset) % n], M // 2, s1, M // 2)
+            e0, e1 = torch.cuda.Event(), torch.cuda.Event()
+            e0.record(s0); e1.record(s1)
+            main.wait_event(e0); main.wait_event(e1)
+
+        t_seq = timeit(seq)
+        res = [f"sequential full-M {t_seq * 1e3:.0f} us"]
+        for off in range(len(gs)):
+            res.append(f"two streams offset {off}: {timeit(lambda: two(off)) * 1e3:.0f} us")
+        print(name + ": " + "; ".join(res), flush=True)
