@@ -39,7 +39,12 @@ import torch.distributed as dist  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
-MFMA_KERNELS = ("conv1d_mfma", "gemm_tn", "gemm_bf16x3", "flash_attn")
+# Kernel families are named after the kernel function they time, as rocprofv3 prints it (csrc/prof.h): a family's line below matches
+# the rows of profiles/rNN_*_kernel_stats.csv whose name contains it.
+MFMA_KERNELS = ("conv1d_mfma_kernel", "conv1d_bf16x3_kernel", "gemm_tn_kernel", "gemm_bf16x3", "flash_attn")
+SPLIT_BF16_KERNELS = ("conv1d_bf16x3_kernel", "gemm_bf16x3", "flash_attn_bf16x3_kernel", "flash_attn_planes_kernel")
+DECODE_KERNELS = ("gemv_fx_kernel", "gemv_fx_combine_kernel", "decode_attn_kernel", "sample_greedy_kernel", "sample_warp_kernel", "embed_step_kernel",
+                  "advance_state_kernel", "beam_")
 
 
 def log(*a):
@@ -60,7 +65,7 @@ def roofline_from_profile(prof, steps, workload="pipeline", split_bf16=True, def
     dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["net_ms"])
     if dom_name.startswith(MFMA_KERNELS):
         achieved = dom["flops"] / dom["ms"] / 1e9
-        if dom_name.startswith("gemm_bf16x3") or (split_bf16 and dom_name.startswith(("conv1d_mfma", "flash_attn"))):
+        if dom_name.startswith(SPLIT_BF16_KERNELS):
             # split-bf16: every algorithmic multiply-add is executed as three bf16 MFMA products, so the dense bf16 peak,
             # expressed in ALGORITHMIC flops, is 2500/3 TFLOP/s
             peak, note = PEAK_BF16_MFMA_TFLOPS / 3.0, "dense bf16 MFMA peak 2500 TFLOP/s / 3 products per fp32-class product"
@@ -76,11 +81,11 @@ def roofline_from_profile(prof, steps, workload="pipeline", split_bf16=True, def
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (separate --pmc FETCH_SIZE /
     # WRITE_SIZE runs, gfx950 correction applied; profiles/README.md) -- null when no pass is on file for this kernel
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic_r02.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "traffic_r03.json")) as f:
             tr = json.load(f)["kernels"].get(dom_name)
         if tr and workload == "pipeline" and default_config:      # the PMC passes on file are of the default configs[2] command
             r["traffic"] = tr["hbm_bytes_per_launch"]
-            r["traffic_source"] = "profiles/traffic_r02.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes = (2*FETCH+WRITE)*1024)"
+            r["traffic_source"] = "profiles/traffic_r03.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes = (2*FETCH+WRITE)*1024)"
     except (OSError, KeyError, ValueError):
         pass
     r["launches_per_step"] = dom["launches"] // steps
@@ -89,7 +94,39 @@ def roofline_from_profile(prof, steps, workload="pipeline", split_bf16=True, def
     r["kernel_time_share"] = {k: round(v["net_ms"] / tot_ms, 4) for k, v in prof.items()}
     r["kernel_ms_per_step"] = {k: round(v["net_ms"] / steps, 3) for k, v in prof.items()}
     r["kernel_ms_per_step_raw"] = {k: round(v["ms"] / steps, 3) for k, v in prof.items()}
+    r["kernel_launches_per_step"] = {k: v["launches"] // steps for k, v in prof.items()}
+    r["kernel_names"] = "kernel function names as rocprofv3 prints them (csrc/prof.h): match profiles/*_kernel_stats.csv rows by substring"
     return r
+
+
+def stage_rooflines(stages, prof, nprof, B, L, M, Tp, Tg, n_cfm, w_bytes_per_param, kv_bytes=4):
+    """One roofline per stage of the step (the step's time is split three ways: HBM-bound decode, MFMA-bound s2mel and vocoder).
+    Work units are SURVEY.md 8(d)'s: GPT decode bytes/step = W + B*S*2*24*1280*sizeof(kv), W = 482.76 M params; s2mel flops =
+    N*2B*T*(148.4e6 + 26624*T) (what the reference executes; the solver here skips the prompt frames' post-transformer part, so it
+    EXECUTES less); BigVGAN 1.80e9 flop per mel frame.  Split-bf16 stages are priced against 2500 / 3 TFLOP/s."""
+    out = {}
+    P = L + 36 + 1                      # [pad | 34 cond | start, text, stop] + start_mel
+    dec_bytes = sum(482.76e6 * w_bytes_per_param + B * (P + n) * 2 * 24 * 1280 * kv_bytes for n in range(M))
+    t = stages.get("gpt_gen_time")
+    if t:
+        dec_launches = sum(v["launches"] for k, v in prof.items() if k.startswith(DECODE_KERNELS)) / max(nprof, 1)
+        out["gpt_decode"] = {"bound": "hbm", "alg_bytes_per_step": dec_bytes, "seconds": t, "achieved": round(dec_bytes / t / 1e9, 1), "peak": PEAK_HBM_GBS,
+                             "unit": "GB/s", "frac": round(dec_bytes / t / 1e9 / PEAK_HBM_GBS, 4), "launches_per_token": round(dec_launches / M, 1),
+                             "us_per_token": round(1e6 * t / M, 1), "kv_cache": "fp32", "note": "gpt_gen_time includes the prefill (165 tokens, MFMA)"}
+    T = Tp + Tg
+    s2_flops = n_cfm * 2 * B * T * (148.4e6 + 26624.0 * T)
+    t = stages.get("s2mel_time")
+    if t:
+        out["s2mel"] = {"bound": "mfma", "alg_flops_per_step": s2_flops, "seconds": t, "achieved": round(s2_flops / t / 1e12, 1),
+                        "peak": round(PEAK_BF16_MFMA_TFLOPS / 3, 1), "unit": "TFLOP/s", "frac": round(s2_flops / t / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3), 4),
+                        "note": "reference-algorithm flops (all frames); split-bf16 = 3 bf16 MFMAs per product"}
+    v_flops = 1.80e9 * B * Tg
+    t = stages.get("bigvgan_time")
+    if t:
+        out["bigvgan"] = {"bound": "mfma", "alg_flops_per_step": v_flops, "seconds": t, "achieved": round(v_flops / t / 1e12, 1),
+                          "peak": round(PEAK_BF16_MFMA_TFLOPS / 3, 1), "unit": "TFLOP/s", "frac": round(v_flops / t / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3), 4),
+                          "note": "stages with >= 192 channels are MFMA-bound, the narrow stages and the anti-alias activations HBM-bound (per-kernel lines)"}
+    return out
 
 
 def cpu_threads():
@@ -144,7 +181,7 @@ def build_vocoder(args, world, rank, dev):
 def build_pipeline(args, world, rank, dev):
     from indextts_amd import synth, weights
     from indextts_amd.config import PipelineConfig
-    from indextts_amd.dist import broadcast_conditioning, gather_waveforms
+    from indextts_amd.dist import ShardedSynthesizer, shard_bounds
     from indextts_amd.infer_v2 import IndexTTS2, PromptConditioning
     cfg = PipelineConfig()
     B, L, M, Tp = args.batch or 16, args.text_tokens, args.codes, args.prompt_frames
@@ -161,19 +198,28 @@ def build_pipeline(args, world, rank, dev):
         wg = tts.gpt.effective_state_dict
     cond0 = PromptConditioning.synthetic(cfg, prompt_frames=Tp, tag="bench/prompt")
     shapes = cond0.shapes()
-    text = torch.from_numpy(synth.integers(f"bench/text/rank{rank}", (B, L), 2, cfg.gpt.number_text_tokens))
+    # The job's utterance list: B per GPU (rank 0 holds all of it: ShardedSynthesizer scatters the ids and gathers the waveforms);
+    # utterance i has its own token ids and CFM noise, the same whichever rank synthesises it.
     Tg = int(M * cfg.code_to_frame)
+    n_all = B * world
+    lo_r, hi_r = shard_bounds(n_all, world, rank)
+    text_all = torch.cat([torch.from_numpy(synth.integers(f"bench/text/rank{r}", (B, L), 2, cfg.gpt.number_text_tokens)) for r in range(world)])
+    text = text_all[lo_r:hi_r]
     noise = torch.from_numpy(synth.uniform(f"bench/noise/rank{rank}", (B, cfg.s2mel.in_channels, Tp + Tg), 1.7)).to(dev)
     cond_dev = cond0.to(dev)
     audio_s = B * Tg * cfg.bigvgan.total_upsample / cfg.bigvgan.sampling_rate
     warnings.filterwarnings("ignore", category=RuntimeWarning)
 
+    def noise_rows(idx):        # CFM noise of the utterances `idx` (global indices; all inside this rank's shard)
+        return noise[[i - lo_r for i in idx]]
+
     def step_sequential(last=False):
-        c = broadcast_conditioning(cond_dev if rank == 0 else None, shapes, dev) if world > 1 else cond_dev
-        wavs = tts.synthesize_batch(text, c, max_mel_tokens=M, noise=noise)
         if world > 1:
-            gather_waveforms(wavs, dst=0, same_count=True)
-        return wavs[0]
+            sh = ShardedSynthesizer(tts, batch_size=16)
+            h = sh.begin(text_all.tolist() if rank == 0 else None, cond_dev if rank == 0 else None, shapes, max_mel_tokens=M, noise_fn=noise_rows)
+            sh.finish(h)
+            return h["local"][0]
+        return tts.synthesize_batch(text, cond_dev, max_mel_tokens=M, noise=noise)[0]
 
     # Software pipeline ACROSS steps (default; indextts_amd/serving.py): `--decode-lanes` decode chains of consecutive batches in
     # flight at once -- latency-bound chains of 125 small launches per token that leave most CUs idle and interleave almost for
@@ -190,16 +236,22 @@ def build_pipeline(args, world, rank, dev):
         pipe.trace = []
     pending = []
 
-    def retire(fut):
-        wavs = fut.result()
-        if world > 1:
-            gather_waveforms(wavs, dst=0, same_count=True)
-        return wavs[0]
+    sharder = ShardedSynthesizer(tts, batch_size=16, pipeline=pipe) if (world > 1 and pipe is not None) else None
+    per_step = max(1, (hi_r - lo_r + 15) // 16)       # batches of 16 one step puts into this rank's pipeline
+
+    def retire(job):
+        if sharder is not None:
+            sharder.finish(job)                        # gather to rank 0 + original order (collectives on the main thread)
+            return job["local"][0]
+        return job.result()[0]
 
     def step_pipelined(last=False):
-        c = broadcast_conditioning(cond_dev if rank == 0 else None, shapes, dev) if world > 1 else cond_dev
-        out = retire(pending.pop(0)) if len(pending) > lanes else None       # at most lanes + 1 batches in flight
-        pending.append(pipe.submit(text, c, max_mel_tokens=M, noise=noise))
+        out = retire(pending.pop(0)) if len(pending) * per_step > lanes else None       # about lanes + 1 batches in flight
+        if sharder is not None:
+            pending.append(sharder.begin(text_all.tolist() if rank == 0 else None, cond_dev if rank == 0 else None, shapes,
+                                         max_mel_tokens=M, noise_fn=noise_rows))
+        else:
+            pending.append(pipe.submit(text, cond_dev, max_mel_tokens=M, noise=noise))
         return out
 
     flushed = []
@@ -245,7 +297,8 @@ def build_pipeline(args, world, rank, dev):
             f"mel L1={mel_l1:.2e}, max|wav| diff={wav_err:.2e} (full scale)")
         return {"value": round(caudio / cdt, 4), "unit": "audio_s/s", "cores": cores, "kind": "port",
                 "sample": f"oracle/pipeline.py (fp32 torch CPU): 1 utterance, {Lc} text tokens, {Mc} codes ({caudio:.2f} s audio), "
-                          f"Tp={Tp}, {cfg.diffusion_steps} CFM steps, full-size weights",
+                          f"Tp={Tp}, {cfg.diffusion_steps} CFM steps, full-size weights (the B = 16 x 512-code batch of the GPU run would "
+                          f"take the oracle ~20 minutes: BASELINE.md 3's B = 16 leg does not fit the bounded sample)",
                 "greedy_codes_equal_vs_gpu": codes_equal, "mel_l1_vs_gpu": mel_l1, "wav_max_abs_diff_vs_gpu_fullscale": wav_err}
 
     desc = {"workload": f"{'configs[4] (long-form, emotion vector, fp8 GPT weights, graph-replayed decode)' if args.longform else 'configs[2]'}: IndexTTS-2 full pipeline (gpt 472M + s2mel 98M + BigVGAN 112M params), batch {B} utterances per "
@@ -258,10 +311,75 @@ def build_pipeline(args, world, rank, dev):
                             f"software pipeline across steps: {lanes} decode chain(s) of consecutive batches in flight (one stream + host thread "
                             "each), one s2mel+vocoder stage at a time behind them on its own stream; every batch inside the timed region")
     step.flush = (lambda: None) if args.no_overlap else flush
-    step.reference = lambda: tts.synthesize_batch(text, cond_dev, max_mel_tokens=M, noise=noise)[0]
+    nref = 16 if world > 1 else len(text)        # multi-rank: a shard goes through the pipeline in batches of 16
+    step.reference = lambda: tts.synthesize_batch(text[:nref], cond_dev, max_mel_tokens=M, noise=noise[:nref])[0]
     step.flushed = flushed
     step.pipe = pipe
     return step, profiled, cpu_leg, stage_times, audio_s, desc
+
+
+def _prompt_audio(tag, sr, seconds):
+    from indextts_amd import synth
+    n = int(sr * seconds)
+    t = np.arange(n) / sr
+    return (0.4 * np.sin(2 * np.pi * (180 + 40 * np.sin(2 * np.pi * 1.3 * t)) * t) + 0.1 * np.sin(2 * np.pi * 1900 * t)
+            + 0.05 * synth.uniform(tag, (n,), 1.0)).astype(np.float32)
+
+
+def build_prompt_or_infer(args, world, rank, dev):
+    """The two things the prompt block and the reference-default decoding mode (8f2) exist for:
+      prompt         15 s speaker prompt + 15 s emotion prompt -> PromptConditioning (w2v-bert 17 layers, semantic codec, mel, CAMPPlus,
+                     length regulator, conformer + perceiver + emotion vector; infer_v2.py:618-666, 681-696, 748-754): the cache-miss
+                     latency of a request.  value = prompt encodes per second, ms_per_step = the latency.
+      infer_default  IndexTTS2.infer() as the reference runs it by default (infer_v2.py:714-722: do_sample, num_beams = 3, top_p .8, top_k 30,
+                     temperature .8, repetition_penalty 10) on ONE sentence, B = 1, warm prompt cache (cold = + the prompt workload's latency).
+                     value = audio seconds per wall second."""
+    from indextts_amd import synth, weights
+    from indextts_amd.config import CamPPlusConfig, PipelineConfig, RepCodecConfig, W2VBertConfig
+    from indextts_amd.infer_v2 import IndexTTS2, PromptConditioning
+    from indextts_amd.prompt import PromptAudio, PromptEncoders
+    cfg = PipelineConfig()
+    t0 = time.time()
+    wg = weights.synth_gpt_weights(cfg.gpt, tag="bench/gpt")
+    wg.update(weights.synth_gpt_cond_weights(cfg.gpt, tag="bench/gpt"))
+    M = args.codes
+    wg["mel_head.bias"][cfg.gpt.stop_mel_token] = -1e4      # fixed length: exactly M codes
+    ws = weights.synth_s2mel_weights(cfg.s2mel, tag="bench/s2mel")
+    wv = weights.synth_bigvgan_weights(cfg.bigvgan, tag="bench/bigvgan")
+    wcfg, ccfg, pcfg = W2VBertConfig(), RepCodecConfig(), CamPPlusConfig()
+    wc = weights.synth_repcodec_weights(ccfg, tag="bench/codec")
+    for k in ("codebook.weight", "out_project.weight", "out_project.bias"):
+        ws[f"semantic_codec.quantizer.quantizers.0.{k}"] = wc[f"quantizer.quantizers.0.{k}"]
+    tts = IndexTTS2.from_state_dicts(cfg, wg, ws, wv, device=dev, gpt_weight_format=args.gpt_weights)
+    tts.prompt_encoders = PromptEncoders(weights.synth_w2vbert_weights(wcfg, tag="bench/w2v"), wc, weights.synth_campplus_weights(pcfg, tag="bench/campplus"),
+                                         tts.s2mel, device=dev, w2vbert_cfg=wcfg, codec_cfg=ccfg, campplus_cfg=pcfg)
+    log(f"[bench] synthetic weights + contexts in {time.time() - t0:.1f}s")
+    secs = args.prompt_seconds
+    spk = PromptAudio(_prompt_audio("bench/p16", 16000, secs), _prompt_audio("bench/p22", 22050, secs))
+    emo = PromptAudio(_prompt_audio("bench/e16", 16000, secs))
+    warnings.filterwarnings("ignore", category=RuntimeWarning)
+    if args.workload == "prompt":
+        def step():
+            feats = tts.prompt_encoders.encode(spk, emo)
+            c = PromptConditioning.from_features(tts.gpt, feats, emo_alpha=0.7)
+            return c.spk_cond_latent
+        desc = {"workload": f"prompt block (SURVEY 8f1): {secs:.0f} s speaker prompt + {secs:.0f} s emotion prompt -> PromptConditioning, full-size encoders "
+                            "(w2v-bert-2.0 17 layers, RepCodec, CAMPPlus, mel, length regulator, conformer 6x512 + perceiver, emotion pair)",
+                "prompt_seconds": secs, "unit_note": "value = prompt encodes per second; ms_per_step = cache-miss latency of one request"}
+        return step, step, None, None, 1.0, desc
+    seg = synth.integers("bench/sentence", (1, args.text_tokens), 2, cfg.gpt.number_text_tokens).tolist()
+    G = dict(max_mel_tokens=M)          # everything else: the reference's defaults (beam-sample, 3 beams)
+    audio = {}
+
+    def step():
+        sr, a = tts.infer(spk, seg, None, emo_audio_prompt=emo, emo_alpha=0.7, **G)
+        audio["s"] = a.shape[0] / sr
+        return torch.from_numpy(a.astype(np.float32))
+    step()      # cold call: fills the prompt caches (its latency = the prompt workload's + one warm call)
+    desc = {"workload": f"IndexTTS2.infer() reference defaults (infer_v2.py:714-722: beam-sample, num_beams 3, top_p 0.8, top_k 30, temperature 0.8, "
+                        f"rep-penalty 10): ONE sentence of {args.text_tokens} text tokens, B = 1, {M} codes, warm prompt cache",
+            "text_tokens": args.text_tokens, "codes": M}
+    return step, step, None, None, audio["s"], desc
 
 
 def launcher_command(argv, n_gpus: int, port: int):
@@ -292,7 +410,8 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "vocoder", "longform"],
+    ap.add_argument("--prompt-seconds", type=float, default=15.0, help="prompt / infer_default workloads: length of the speaker and emotion prompts")
+    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "vocoder", "longform", "prompt", "infer_default"],
                     help="pipeline = BASELINE configs[2] (the metric's configuration); vocoder = configs[1]; longform = configs[4]: ONE "
                          "utterance of 1500 codes (30 s), emotion vector mixed in, fp8 GPT weights, graph-replayed decode")
     ap.add_argument("--batch", type=int, default=0)
@@ -327,7 +446,10 @@ def main() -> int:
     if longform:
         args.workload = "pipeline"
         args.batch = args.batch or 1
-    args.codes = args.codes or (1500 if longform else 512)
+    side = args.workload in ("prompt", "infer_default")
+    if args.workload == "infer_default" and args.text_tokens == 128:
+        args.text_tokens = 40                      # one sentence
+    args.codes = args.codes or (1500 if longform else (200 if side else 512))
     # configs[2] names bf16 ("IndexTTS-2 full pipeline ... batch=16, 1xMI355X, bf16, greedy decode"), configs[4] fp8: the GPT's linear
     # weights are STORED in that format (rounded once at load), the arithmetic stays fp32, and the parity leg runs the same rounded
     # model on the CPU oracle.  --gpt-weights f32 keeps the reference's own weights bit for bit.
@@ -360,7 +482,7 @@ def main() -> int:
     _lib.set_gemm_mode(0 if args.gemm == "f32" else 1)
     _lib.set_s2mel_overlap(bool(args.s2mel_overlap))
     t0 = time.time()
-    build = build_pipeline if args.workload == "pipeline" else build_vocoder
+    build = build_pipeline if args.workload == "pipeline" else (build_prompt_or_infer if side else build_vocoder)
     step, profiled, cpu_leg, stage_times_fn, audio_s_per_step_per_gpu, desc = build(args, world, rank, dev)
     log(f"[bench] rank {rank}: model + inputs ready in {time.time() - t0:.1f}s")
 
@@ -405,7 +527,7 @@ def main() -> int:
         log(f"[bench] rank {rank}: {len(outs)} pipelined outputs equal the sequential synthesize_batch bit for bit: {equal_seq}")
         assert equal_seq, "a pipelined batch differs from the sequential result"
 
-    roofline = stages = None
+    roofline = stages = roofline_stages = None
     if rank == 0 and not args.no_roofline:
         # same work again with per-launch HIP events on the launch stream (graph replay is bypassed while profiling)
         empty_ms = _lib.profile_event_overhead(400)
@@ -432,9 +554,13 @@ def main() -> int:
         log(f"[bench] event-pair reading around an empty launch {1000 * empty_ms:.2f} us; per-launch cost of the bracketing {1000 * overhead_ms:.2f} us")
         roofline = roofline_from_profile(prof, nprof, args.workload, split_bf16=args.gemm != "f32", default_config=default_cfg,
                                          overhead_ms=overhead_ms)
+        if stages and args.workload == "pipeline":
+            wb = {"f32": 4, "bf16": 2, "fp8": 1}[args.gpt_weights]
+            roofline_stages = stage_rooflines(stages, prof, nprof, desc["batch_per_gpu"], desc["text_tokens"], desc["codes"], desc["prompt_frames"],
+                                              int(desc["codes"] * 1.72), desc["diffusion_steps"], wb)
 
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and cpu_leg is not None:
         cpu_baseline = cpu_leg()
 
     if rank == 0:
@@ -451,7 +577,8 @@ def main() -> int:
         value = audio_total / elapsed
         cfgd = dict(desc)
         cfgd.update({"parallelism": f"dp{world}",
-                     "exchange": "broadcast(conditioning)+gather(waveforms)->rank0" if world > 1 else "none",
+                     "exchange": ("ShardedSynthesizer: broadcast(token ids + conditioning) from rank 0, sort by length, contiguous shards, "
+                                  "gather(waveforms) -> rank 0 in the original order") if world > 1 else "none",
                      "collective_backend": (dist.get_backend() if world > 1 else "none"),
                      "collective_ranks": (dist.get_world_size() if world > 1 else 1),
                      "timed_region": "inputs (token ids, conditioning, CFM noise) already resident in HBM; waveforms stay on the device "
@@ -464,14 +591,17 @@ def main() -> int:
         if world >= 8 and cfgd.get("batch_per_gpu") == 32 and not longform:
             cfgd["workload"] = cfgd["workload"].replace("configs[2]", f"configs[3] ({32 * world} utterances sharded data-parallel, 32 per GPU)")
         res = {
-            "metric": "synthesised audio seconds per second (IndexTTS-2 infer_v2 hot path), whole job",
-            "value": round(value, 2), "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": ("prompt encodes per second (speaker + emotion prompt -> PromptConditioning)" if args.workload == "prompt" else
+                       "synthesised audio seconds per second (IndexTTS-2 infer_v2 hot path), whole job"),
+            "value": round(value, 2), "unit": "prompts/s" if args.workload == "prompt" else "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype,
             "data": "synthetic (seeded random-init weights of the full architecture, synthetic prompt features and token ids)",
             "config": cfgd, "audio_s_per_s_per_gpu": round(value / world, 2), "rtf": round(elapsed / audio_total, 6),
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        if roofline_stages:
+            res["roofline_stages"] = roofline_stages
         if stages:
             res["stage_seconds"] = stages
             ntok = cfgd["batch_per_gpu"] * cfgd["codes"]

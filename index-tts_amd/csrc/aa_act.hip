@@ -253,7 +253,8 @@ int aa_act_forward(void* y, const void* x, const float* up_f, const float* down_
   IDX_CHECK(C <= 65535 && B <= 65535, "grid y/z limit");
   AAParams p{x, y, up_f, down_f, log_alpha, log_beta, C, T, lens, len_mul};
   dim3 grid(cdiv(cdiv(T, AA_TILE), AA_TPW), C, B);
-  ProfScope prof(PROF_AA_ACT, stream, 0.0, 8.0 * B * C * (double)T);   // one read + one write per element
+  static const int cat = prof_register("aa_act_kernel");
+  ProfScope prof(cat, stream, 0.0, 8.0 * B * C * (double)T);   // one read + one write per element
   IDX_CHECK(dtype >= 0 && dtype <= 2, "dtype: 0 float32, 1 float16, 2 bfloat16");
   if (dtype == 0) {
     if (lens) hipLaunchKernelGGL((aa_act_kernel<true, 0>), grid, dim3(256), 0, stream, p);

@@ -707,7 +707,8 @@ int flash_attn_planes_forward(const AttnPlanesArgs& a, hipStream_t stream) {
   dim3 grid((unsigned)(pairs8 * k.nqblk));
   const double flops = 4.0 * a.B * a.H * (double)a.Sq * a.T * 64;
   const double bytes = 4.0 * a.B * a.H * 64.0 * (2.0 * a.Sq + 2.0 * a.T);
-  ProfScope prof(PROF_FLASH_ATTN, stream, flops, bytes);
+  static const int cat = prof_register("flash_attn_planes_kernel");
+  ProfScope prof(cat, stream, flops, bytes);
   hipLaunchKernelGGL(flash_attn_planes_kernel, grid, dim3(256), 0, stream, k);
   IDX_LAUNCH_CHECK();
   return 0;
@@ -722,7 +723,8 @@ int flash_attn_forward(const AttnArgs& a, hipStream_t stream) {
   dim3 grid(cdiv(a.Sq, 128), a.H, a.B);
   const double flops = 4.0 * a.B * a.H * (double)a.Sq * a.Sk * 64 * (a.causal ? 0.5 : 1.0);
   const double bytes = 4.0 * a.B * a.H * 64.0 * (2.0 * a.Sq + 2.0 * a.Sk);
-  ProfScope prof(PROF_FLASH_ATTN, stream, flops, bytes);
+  static const int cat_x3 = prof_register("flash_attn_bf16x3_kernel"), cat_f32 = prof_register("flash_attn_f32_kernel");
+  ProfScope prof(a.split_bf16 ? cat_x3 : cat_f32, stream, flops, bytes);
   if (a.split_bf16) hipLaunchKernelGGL(flash_attn_bf16x3_kernel, grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(flash_attn_f32_kernel, grid, dim3(256), 0, stream, a);
   IDX_LAUNCH_CHECK();

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(1024) void beam_scores_kernel(const BeamState p) {
 int beam_scores_forward(const BeamState& s, hipStream_t st) {
   IDX_CHECK(s.logits && s.proc && s.seen && s.beam_scores && s.done, "null pointer");
   IDX_CHECK(s.V > 0 && s.V <= 1024 * NPT && s.nb >= 2 && s.nb <= BEAM_MAX, "beam shape");
-  ProfScope prof(PROF_SAMPLE, st, 0.0, 8.0 * s.B * s.nb * (double)s.V);
+  static const int cat = prof_register("beam_scores_kernel");
+  ProfScope prof(cat, st, 0.0, 8.0 * s.B * s.nb * (double)s.V);
   hipLaunchKernelGGL(beam_scores_kernel, dim3(s.B * s.nb), dim3(1024), 0, st, s);
   IDX_LAUNCH_CHECK();
   return 0;
@@ -339,7 +340,8 @@ int beam_reorder_forward(const BeamState& s, hipStream_t st) {
   IDX_CHECK(s.seq && s.seen && s.cur_tok && s.kcache && s.vcache && s.beam_idx && s.next_tok, "null pointer");
   hipLaunchKernelGGL(beam_reorder_rows_kernel, dim3(s.B), dim3(1024), 0, st, s);
   IDX_LAUNCH_CHECK();
-  ProfScope prof(PROF_ELTWISE, st, 0.0, 0.0);
+  static const int cat = prof_register("beam_select_kernel + beam_reorder_rows_kernel + beam_reorder_kv_kernel");
+  ProfScope prof(cat, st, 0.0, 0.0);
   hipLaunchKernelGGL(beam_reorder_kv_kernel, dim3(256, s.B), dim3(256), 0, st, s);
   IDX_LAUNCH_CHECK();
   return 0;

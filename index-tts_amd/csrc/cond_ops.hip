@@ -69,7 +69,8 @@ int sub2_conv_relu(float* a, const float* x, const float* w, const float* bias, 
   const int T2 = (T - 3) / 2 + 1, F2 = (F - 3) / 2 + 1;
   const size_t lds = (size_t)(3 * F + 10 * C) * sizeof(float);
   IDX_CHECK(lds <= 64 * 1024, "input row / filter bank too large for LDS");
-  ProfScope prof(PROF_ELTWISE, st, 18.0 * B * T2 * (double)C * F2, 4.0 * ((double)B * T * F + (double)B * T2 * C * F2));
+  static const int cat = prof_register("sub2_conv_relu_kernel");
+  ProfScope prof(cat, st, 18.0 * B * T2 * (double)C * F2, 4.0 * ((double)B * T * F + (double)B * T2 * C * F2));
   hipLaunchKernelGGL(sub2_conv_relu_kernel, dim3(T2, B), dim3(256), lds, st, a, x, w, bias, T, F, C, T2, F2);
   IDX_LAUNCH_CHECK();
   return 0;
@@ -158,7 +159,8 @@ int seq_attn_forward(const SeqAttnArgs& a, hipStream_t st) {
   const int nrel4 = a.rel_key ? (a.rel_left + a.rel_right + 1 + 3) & ~3 : 0;
   const size_t lds = (size_t)4 * (2 * a.dk + nrel4 + ((a.Sk + 3) & ~3)) * sizeof(float);
   IDX_CHECK(lds <= 64 * 1024, "key sequence too long for the short-sequence attention kernel");
-  ProfScope prof(PROF_ELTWISE, st, (a.pos ? 6.0 : 4.0) * a.B * a.H * (double)a.Sq * a.Sk * a.dk,
+  static const int cat = prof_register("seq_attn_kernel");
+  ProfScope prof(cat, st, (a.pos ? 6.0 : 4.0) * a.B * a.H * (double)a.Sq * a.Sk * a.dk,
                  4.0 * a.B * a.H * a.dk * (2.0 * a.Sq + 2.0 * a.Sk));
   hipLaunchKernelGGL(seq_attn_kernel, dim3(cdiv(a.Sq, 4), a.H, a.B), dim3(256), lds, st, a);
   IDX_LAUNCH_CHECK();
@@ -229,7 +231,8 @@ int glu_dwconv_ln_silu(float* y, const float* pw, const float* wdw, const float*
                        int D, int k, hipStream_t st, int pad_left) {
   IDX_CHECK(y && pw && wdw && gamma && beta, "null pointer");
   IDX_CHECK(B > 0 && T > 0 && D > 0 && D <= 256 * DW_MAX_PER_THREAD && (k & 1) == 1 && pad_left < k, "shape");
-  ProfScope prof(PROF_ELTWISE, st, 0.0, 4.0 * B * T * 3.0 * D);
+  static const int cat = prof_register("dwconv_ln_kernel<true, true>");
+  ProfScope prof(cat, st, 0.0, 4.0 * B * T * 3.0 * D);
   hipLaunchKernelGGL((dwconv_ln_kernel<true, true>), dim3(B * T), dim3(256), 0, st, y, pw, wdw, bdw, gamma, beta, T, D, k,
                      pad_left < 0 ? (k - 1) / 2 : pad_left, 1e-5f);
   IDX_LAUNCH_CHECK();
@@ -240,7 +243,8 @@ int dwconv_ln(float* y, const float* x, const float* wdw, const float* bdw, cons
               float eps, hipStream_t st) {
   IDX_CHECK(y && x && wdw && gamma && beta, "null pointer");
   IDX_CHECK(B > 0 && T > 0 && D > 0 && D <= 256 * DW_MAX_PER_THREAD && (k & 1) == 1, "shape");
-  ProfScope prof(PROF_ELTWISE, st, 0.0, 4.0 * B * T * 2.0 * D);
+  static const int cat = prof_register("dwconv_ln_kernel<false, false>");
+  ProfScope prof(cat, st, 0.0, 4.0 * B * T * 2.0 * D);
   hipLaunchKernelGGL((dwconv_ln_kernel<false, false>), dim3(B * T), dim3(256), 0, st, y, x, wdw, bdw, gamma, beta, T, D, k, (k - 1) / 2, eps);
   IDX_LAUNCH_CHECK();
   return 0;

@@ -21,6 +21,8 @@
 #include "conv1d.h"
 #include "conv_epilogue.h"
 #include "gemm.h"
+#include <string>
+
 #include "prof.h"
 
 namespace idxtts {
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256, (TM == 3 ? 2 : 3)) void conv1d_mfma_kernel(con
   conv_epilogue<TM, TN>(p, acc, m_blk * BM + wm * TM * 32, t0 + wn * TN * 32, b, T, h, j);
 }
 
-template <int TM, int TN, int WGM, int WGN, int CAT>
+template <int TM, int TN, int WGM, int WGN>
 static int launch_conv(const ConvWeights& w, const ConvArgs& a, hipStream_t stream) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, NSUB = TM * WGM;
   ConvKP p;
@@ -269,7 +271,8 @@ static int launch_conv(const ConvWeights& w, const ConvArgs& a, hipStream_t stre
     const double flops = 2.0 * cout * w.Cin * taps * tout;
     const double bytes = 4.0 * ((double)a.B * w.Cin * a.T + cout * tout * (1.0 + (a.res ? 1.0 : 0.0) + (a.accum ? 1.0 : 0.0)) +
                                 cout * w.Cin * (w.ups > 1 ? 2.0 * w.ups : (double)w.K));
-    ProfScope prof(CAT, stream, flops, bytes);
+    static const int cat = prof_register(("conv1d_mfma_kernel<" + std::to_string(TM) + ", " + std::to_string(TN) + ", " + std::to_string(WGM) + ", " + std::to_string(WGN) + ">").c_str());
+    ProfScope prof(cat, stream, flops, bytes);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p);
   }
   IDX_LAUNCH_CHECK();
@@ -281,10 +284,10 @@ int conv1d_forward(const ConvWeights& w, const ConvArgs& a, hipStream_t stream) 
   IDX_CHECK(a.B > 0 && a.T > 0, "empty shape");
   if (a.pad_mode == PAD_REFLECT) IDX_CHECK(a.T > (w.K - 1) * a.dil, "reflect pad needs T > halo");
   if (w.wp16 && get_gemm_mode() == GEMM_BF16X3) return conv1d_bf16x3_forward(w, a, stream);
-  if (w.M > 96) return launch_conv<2, 2, 2, 2, PROF_CONV_128x128>(w, a, stream);   // 128 x 128
-  if (w.M > 64) return launch_conv<3, 2, 1, 4, PROF_CONV_96x256>(w, a, stream);   //  96 x 256
-  if (w.M > 32) return launch_conv<2, 2, 1, 4, PROF_CONV_64x256>(w, a, stream);   //  64 x 256
-  return launch_conv<1, 4, 1, 4, PROF_CONV_32x512>(w, a, stream);                 //  32 x 512
+  if (w.M > 96) return launch_conv<2, 2, 2, 2>(w, a, stream);   // 128 x 128
+  if (w.M > 64) return launch_conv<3, 2, 1, 4>(w, a, stream);   //  96 x 256
+  if (w.M > 32) return launch_conv<2, 2, 1, 4>(w, a, stream);   //  64 x 256
+  return launch_conv<1, 4, 1, 4>(w, a, stream);                 //  32 x 512
 }
 
 }  // namespace idxtts

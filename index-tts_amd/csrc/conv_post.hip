@@ -64,7 +64,8 @@ int conv_post_forward(float* y, const float* x, const float* w, int B, int C, in
   if (B == 0 || T == 0) return 0;
   ConvPostParams p{x, w, y, C, T, clamp};
   dim3 grid(cdiv(T, 1024), B);
-  ProfScope prof(PROF_CONV_POST, stream, 14.0 * B * C * (double)T, 4.0 * B * (C + 1.0) * (double)T);
+  static const int cat = prof_register("conv_post_kernel");
+  ProfScope prof(cat, stream, 14.0 * B * C * (double)T, 4.0 * B * (C + 1.0) * (double)T);
   hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), (size_t)C * 7 * sizeof(float), stream, p);
   IDX_LAUNCH_CHECK();
   return 0;

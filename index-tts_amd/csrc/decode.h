@@ -19,6 +19,7 @@ struct DecodeAttnArgs {
   const DecodeState* st = nullptr;
   int B = 0, H = 0, Smax = 0, d = 0;
   float scale = 0.125f;
+  int pos_hint = 0;             // cached positions incl. this step as the HOST knows them (profiler accounting only; 0 under graph replay)
   // Key split for small batches (B * H workgroups cannot pull the KV stream through 256 CUs: a CU sustains ~25 GB/s):
   // nsplit > 1 workgroups per (utterance, head) each take a contiguous range of the keys and leave (max, sum, unnormalised
   // output); the last one to arrive merges them in split order (wait-free, decode_attn_nsplit() depends on B and H only).

@@ -235,8 +235,9 @@ int decode_attn_forward(const DecodeAttnArgs& a, hipStream_t stream) {
     attr_set = true;
   }
   IDX_CHECK(a.nsplit >= 1 && a.nsplit <= 16 && (a.nsplit == 1 || (a.part && a.cnt)), "key split: 1..16 pieces, partial buffer and counters");
-  // algorithmic bytes depend on the device-side position; the caller (bench) accounts for them
-  ProfScope prof(PROF_DECODE_ATTN, stream, 0.0, 0.0);
+  // algorithmic bytes: K and V of every cached position, all heads: B * S * 2 * d * 4 (S as the host knows it: pos_hint)
+  static const int cat = prof_register("decode_attn_kernel");
+  ProfScope prof(cat, stream, 0.0, 8.0 * a.B * (double)a.pos_hint * a.d);
   hipLaunchKernelGGL(decode_attn_kernel<512>, dim3(a.H, a.B, a.nsplit), dim3(512), lds, stream, a);
   IDX_LAUNCH_CHECK();
   return 0;
@@ -298,7 +299,8 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs p)
 
 int sample_greedy_forward(const SampleArgs& a, hipStream_t stream) {
   IDX_CHECK(a.part && a.seen && a.finished && a.codes && a.cur_tok && a.st, "null pointer");
-  ProfScope prof(PROF_SAMPLE, stream, 0.0, 4.0 * a.B * (double)a.V * (a.parts + 1));
+  static const int cat = prof_register("sample_greedy_kernel");
+  ProfScope prof(cat, stream, 0.0, 4.0 * a.B * (double)a.V * (a.parts + 1));
   hipLaunchKernelGGL(sample_greedy_kernel, dim3(a.B), dim3(1024), 0, stream, a);
   IDX_LAUNCH_CHECK();
   return 0;
@@ -473,7 +475,8 @@ int sample_warp_forward(const SampleWarpArgs& a, hipStream_t stream) {
   IDX_CHECK(b.V > 0 && b.V <= 1024 * SW_NPT, "vocabulary size");
   IDX_CHECK(a.temperature > 0.0f && a.top_k >= 0 && a.top_p > 0.0f, "sampling parameters");
   IDX_CHECK(a.mode == SAMPLE_HF || a.mode == SAMPLE_ACCEL, "sampling mode");
-  ProfScope prof(PROF_SAMPLE, stream, 0.0, 8.0 * b.B * (double)b.V);
+  static const int cat = prof_register("sample_warp_kernel");
+  ProfScope prof(cat, stream, 0.0, 8.0 * b.B * (double)b.V);
   hipLaunchKernelGGL(sample_warp_kernel, dim3(b.B), dim3(1024), 0, stream, a);
   IDX_LAUNCH_CHECK();
   return 0;
@@ -503,7 +506,8 @@ __global__ __launch_bounds__(256) void kv_store_prefill_kernel(const float* qkv,
 
 int kv_store_prefill(const float* qkv, float* kcache, float* vcache, int B, int H, int S, int Smax, int d, hipStream_t stream) {
   IDX_CHECK(S <= Smax, "prefill longer than the cache");
-  ProfScope prof(PROF_ELTWISE, stream, 0.0, 16.0 * B * (double)S * d);
+  static const int cat = prof_register("kv_store_prefill_kernel");
+  ProfScope prof(cat, stream, 0.0, 16.0 * B * (double)S * d);
   hipLaunchKernelGGL(kv_store_prefill_kernel, dim3(S, B), dim3(256), 0, stream, qkv, kcache, vcache, B, H, S, Smax, d);
   IDX_LAUNCH_CHECK();
   return 0;
@@ -533,7 +537,8 @@ __global__ __launch_bounds__(256) void gather_sum_rows_kernel(const GatherArgs p
 int gather_sum_rows(const GatherArgs& a, int rows, hipStream_t stream) {
   if (rows == 0) return 0;
   IDX_CHECK(a.out && a.d > 0, "gather args");
-  ProfScope prof(PROF_EMBED, stream, 0.0, 8.0 * rows * (double)a.d);
+  static const int cat = prof_register("gather_sum_rows_kernel");
+  ProfScope prof(cat, stream, 0.0, 8.0 * rows * (double)a.d);
   hipLaunchKernelGGL(gather_sum_rows_kernel, dim3(rows), dim3(256), 0, stream, a);
   IDX_LAUNCH_CHECK();
   return 0;
@@ -549,7 +554,8 @@ __global__ __launch_bounds__(256) void embed_step_kernel(float* x, int d, const 
 
 int embed_step(float* x, int B, int d, const float* mel_emb, const float* mel_pos, const int* cur_tok, const DecodeState* st,
                hipStream_t stream) {
-  ProfScope prof(PROF_EMBED, stream, 0.0, 12.0 * B * (double)d);
+  static const int cat = prof_register("embed_step_kernel");
+  ProfScope prof(cat, stream, 0.0, 12.0 * B * (double)d);
   hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(256), 0, stream, x, d, mel_emb, mel_pos, cur_tok, st);
   IDX_LAUNCH_CHECK();
   return 0;

@@ -213,7 +213,8 @@ int gemm_tn_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t strea
   IDX_CHECK(grid < (1ll << 31), "grid size");
   const double flops = 2.0 * a.M * (double)w.N * w.K;
   const double bytes = 4.0 * ((double)a.M * w.K + (double)w.N * w.K + (double)a.M * w.N * (a.res ? 2.0 : 1.0));
-  ProfScope prof(PROF_GEMM_TN, stream, flops, bytes);
+  static const int cat = prof_register("gemm_tn_kernel");
+  ProfScope prof(cat, stream, flops, bytes);
   constexpr size_t lds = (size_t)(2 * 4 * 2 * 4 * XBLK + 2 * 4 * 2 * 512) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {

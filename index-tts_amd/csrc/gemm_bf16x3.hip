@@ -355,7 +355,8 @@ static int launch_big(GemmKP p, const LinearWeights& w, const GemmArgs& a, hipSt
     IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  ProfScope prof(TN == 2 ? PROF_GEMM_BF16X3_256x128 : PROF_GEMM_BF16X3_256x256, stream, flops, bytes);
+  static const int cat = prof_register(TN == 2 ? "gemm_bf16x3_big_kernel<2>" : "gemm_bf16x3_big_kernel<4>");
+  ProfScope prof(cat, stream, flops, bytes);
   hipLaunchKernelGGL(gemm_bf16x3_big_kernel<TN>, dim3((unsigned)grid), dim3(512), lds, stream, p);
   IDX_LAUNCH_CHECK();
   return 0;
@@ -405,7 +406,8 @@ int gemm_bf16x3_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t s
     IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  ProfScope prof(PROF_GEMM_BF16X3, stream, flops, bytes);
+  static const int cat = prof_register("gemm_bf16x3_kernel");
+  ProfScope prof(cat, stream, flops, bytes);
   hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3((unsigned)grid), dim3(256), lds, stream, p);
   IDX_LAUNCH_CHECK();
   return 0;

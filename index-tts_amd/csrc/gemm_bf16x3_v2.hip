@@ -339,7 +339,8 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
   const __bf16* hi = a.x_planes ? static_cast<const __bf16*>(a.x_planes) : static_cast<const __bf16*>(sc.ptr);
   const __bf16* lo = hi + plane / sizeof(__bf16);
   if (!a.x_planes) {
-    ProfScope prof(PROF_ELTWISE, stream, 0.0, 8.0 * a.M * (double)xk);
+    static const int cat_split = prof_register("split_planes_kernel");
+    ProfScope prof(cat_split, stream, 0.0, 8.0 * a.M * (double)xk);
     hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv(a.M, 64), cdiv(xk, 64)), dim3(256), 0, stream, a.x, a.ldx, a.M, xk, const_cast<__bf16*>(hi), const_cast<__bf16*>(lo));
     IDX_LAUNCH_CHECK();
   }
@@ -375,7 +376,8 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
   q.b_plane = (int)b_plane; q.b_bytes = (int)(2 * b_plane);
   const int64_t grid = (int64_t)8 * q.g.nblocks * q.g.mt8;
   IDX_CHECK(grid < (1ll << 31), "grid size");
-  ProfScope prof(PROF_GEMM_BF16X3_256x256, stream, flops, bytes);
+  static const int cat = prof_register("gemm_bf16x3_v2_kernel");
+  ProfScope prof(cat, stream, flops, bytes);
   constexpr int lds = 4 * (2 * 256 * 32 + 2 * 256 * 32);
   const bool paired = a.act == ACT_SWIGLU || a.act == ACT_GATE;
   IDX_CHECK(!(a.rope && (a.res || paired)), "the rotary epilogue takes no residual and no paired activation");

@@ -229,11 +229,7 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmKP& p, f32x16 (&acc
       if (vec) {
         if (EPI != EPI_ROPE && use_res) v += opnd;
         if (masked) v = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifdef V2_NT_STORE
-        if (p.y) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + n_out));
-#else
-        if (p.y) *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + n_out) = v;
-#endif
+        if (p.y) *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + n_out) = v;      // (non-temporal stores measured equal)
         if (p.y_hi) *reinterpret_cast<f32x4*>(lds + rr * RS + ocol) = v;
       } else {                                   // ragged / unaligned columns: element by element (no planes, no rotary)
 #pragma unroll

@@ -488,7 +488,8 @@ __global__ __launch_bounds__(256) void gemv_fx_combine_kernel(const float* __res
 // y (fragment images over N) = res + bias + sum_s slab[s]
 int gemv_fx_combine(const float* slab, int ksb, int rows, int N, const float* bias, const float* res, float* y, hipStream_t stream) {
   IDX_CHECK(slab && y && ksb >= 1 && ksb <= 8 && N % 16 == 0, "combine arguments");
-  ProfScope prof(PROF_ROWS_NORM, stream, 0.0, 4.0 * rows * (double)N * (ksb + 2));
+  static const int cat = prof_register("gemv_fx_combine_kernel");
+  ProfScope prof(cat, stream, 0.0, 4.0 * rows * (double)N * (ksb + 2));
   hipLaunchKernelGGL(gemv_fx_combine_kernel, dim3(cdiv(rows * N, 256)), dim3(256), 0, stream, slab, ksb, rows, N, bias, res, y);
   IDX_LAUNCH_CHECK();
   return 0;
@@ -531,7 +532,8 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
   dim3 grid(cdiv(p.ntiles, ntw), p.ksb);
   const double flops = 2.0 * a.rows * (double)w.N * w.K;
   const double bytes = (double)wfmt_bytes(w.fmt) * w.N * w.K + 4.0 * ((double)a.rows * w.N * (a.res ? 2.0 : 1.0) + (double)a.rows * w.K);
-  ProfScope prof(PROF_GEMV16, stream, flops, bytes);
+  static const int cat = prof_register("gemv_fx_kernel");
+  ProfScope prof(cat, stream, flops, bytes);
 #define LAUNCH_R(MTV, NTWV, SG, WTV, R4V)                                                                                 \
   {                                                                                                                       \
     static bool attr_set = false;                                                                                         \

@@ -299,6 +299,7 @@ int GPTModel::layer_full(int li, const Buffers& w, int B, int S, const int* ksta
 // sampling mode of the generation this host thread is running (mode 0 = greedy)
 static thread_local idxtts_sampling samp{0, 1.0f, 0, 1.0f, nullptr, 0};
 thread_local const BeamState* tl_beam = nullptr;
+static thread_local int tl_prof_pos = 0;      // keys the eager decode step in flight reads (0 while a captured graph replays)
 
 // head on B rows: ln_f -> final_norm (one rows_norm launch, output as fragment images) -> mel_head -> greedy sampler
 int GPTModel::head_and_sample(const Buffers& w, int B, const float* x, int ldx, bool x_frag, float penalty, long long* codes,
@@ -343,6 +344,7 @@ int GPTModel::decode_step(const Buffers& w, int B, float penalty, long long* cod
     da.kcache = w.kcache + li * per_layer; da.vcache = w.vcache + li * per_layer; da.out = w.attd; da.kstart = w.kstart;
     da.st = w.state; da.B = B; da.H = cfg.heads; da.Smax = w.Smax; da.d = d; da.scale = 0.125f;
     da.nsplit = decode_attn_nsplit(B, cfg.heads); da.part = w.attn_part; da.cnt = w.attn_cnt;
+    da.pos_hint = tl_prof_pos;
     if (decode_attn_forward(da, st)) return 1;
     GemvFXArgs pa;      // x += c_proj(attn) + b  (in place: a thread reads and writes only its own element of x)
     pa.xf = w.attd; pa.rows = B; pa.bias = L.proj_l.bias; pa.res = w.xd; pa.y = w.xd; pa.y_frag = 1;
@@ -500,7 +502,9 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
       IDX_HIP(hipGraphLaunch(exec, st));
     } else {
       float* lo = logits_out ? logits_out + (size_t)n * B * V : nullptr;
+      tl_prof_pos = S + n;      // keys this step reads (profiler accounting of the decode attention)
       if (decode_step(w, B, penalty, codes, max_new, lo, st)) return 1;
+      tl_prof_pos = 0;
     }
     steps_done = n + 1;
     if ((n & 15) == 15 || n + 1 == max_new) {     // all rows finished? (HF stops there; later columns would be pad)

@@ -233,7 +233,11 @@ int rows_norm_forward(const RowsNormArgs& a, hipStream_t stream) {
   if (a.mode == NORM_MOD_LN) IDX_CHECK(a.mod_a && a.mod_b, "modulated LN needs shift and scale");
   if (a.in_frag || a.y_frag) IDX_CHECK((a.mode == NORM_LN || a.mode == NORM_LN_LN) && a.d % 16 == 0 && a.in_rows_per_batch == 0, "fragment-image I/O: LayerNorm modes, d % 16 == 0");
   const double bytes = 4.0 * a.M * (double)a.d * (1.0 + a.num_partials + (a.x_out ? 1 : 0) + (a.y ? 1 : 0) + (a.y_planes ? 1 : 0));
-  ProfScope prof(PROF_ROWS_NORM, stream, 0.0, bytes);
+  static const int cat_ada = prof_register("ada_rms_planes512_kernel"), cat_rows = prof_register("rows_norm_kernel");
+  const bool ada512 = a.mode == NORM_ADA_RMS && a.d == 512 && a.y_planes && !a.y && a.x_in && !a.num_partials && !a.add_bias && !a.x_out && !a.in_frag &&
+      a.in_rows_per_batch == 0 && (a.ld_in & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.x_in) | reinterpret_cast<uintptr_t>(a.g1) | reinterpret_cast<uintptr_t>(a.mod_a) |
+                               reinterpret_cast<uintptr_t>(a.mod_b)) & 15) == 0 && (a.ld_mod & 3) == 0;
+  ProfScope prof(ada512 ? cat_ada : cat_rows, stream, 0.0, bytes);
   if (a.mode == NORM_ADA_RMS && a.d == 512 && a.y_planes && !a.y && a.x_in && !a.num_partials && !a.add_bias && !a.x_out && !a.in_frag &&
       a.in_rows_per_batch == 0 && (a.ld_in & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.x_in) | reinterpret_cast<uintptr_t>(a.g1) | reinterpret_cast<uintptr_t>(a.mod_a) |
                                reinterpret_cast<uintptr_t>(a.mod_b)) & 15) == 0 && (a.ld_mod & 3) == 0) {

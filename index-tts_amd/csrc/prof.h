@@ -5,12 +5,12 @@
 
 namespace idxtts {
 
-enum ProfCat {
-  PROF_CONV_128x128 = 0, PROF_CONV_96x256, PROF_CONV_64x256, PROF_CONV_32x512,
-  PROF_AA_ACT, PROF_CONV_POST,
-  PROF_GEMM_TN, PROF_GEMM_BF16X3, PROF_GEMM_BF16X3_256x128, PROF_GEMM_BF16X3_256x256, PROF_FLASH_ATTN, PROF_ROWS_NORM, PROF_GEMV16, PROF_DECODE_ATTN, PROF_SAMPLE, PROF_EMBED, PROF_ELTWISE,
-  PROF_NCAT
-};
+// Families are named after the kernel function they time, as rocprofv3 prints it without "void idxtts::" and the argument list
+// ("gemm_bf16x3_v2_kernel", "conv1d_bf16x3_kernel<2, 2, 2, 2>", ...): every line of bench.py's per-kernel table matches the rows of
+// profiles/rNN_*_kernel_stats.csv whose name contains it.  A launch site registers its family once:
+//     static const int cat = prof_register("decode_attn_kernel");
+constexpr int PROF_MAX = 128;
+int prof_register(const char* kernel_name);   // idempotent, thread-safe
 
 const char* prof_name(int cat);
 bool prof_enabled();

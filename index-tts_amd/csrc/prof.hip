@@ -1,5 +1,6 @@
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "../../include/idxtts.h"
@@ -7,20 +8,27 @@
 
 namespace idxtts {
 
-static const char* kNames[PROF_NCAT] = {
-    "conv1d_mfma_128x128", "conv1d_mfma_96x256", "conv1d_mfma_64x256", "conv1d_mfma_32x512", "aa_act", "conv_post",
-    "gemm_tn_128x128", "gemm_bf16x3_128x128", "gemm_bf16x3_256x128", "gemm_bf16x3_256x256", "flash_attn_f32", "rows_norm", "gemv16_mfma", "decode_attn", "sample_greedy", "embed_rows", "eltwise"};
-
 struct Rec { hipEvent_t a, b; int cat; };
 static std::mutex g_mu;
 static bool g_on = false;
 static std::vector<Rec> g_recs;            // launches recorded since enable
 static std::vector<hipEvent_t> g_pool;     // recycled events
-static double g_flops[PROF_NCAT], g_bytes[PROF_NCAT], g_ms[PROF_NCAT];
-static long g_count[PROF_NCAT];
-static hipEvent_t g_open[PROF_NCAT];
+static double g_flops[PROF_MAX], g_bytes[PROF_MAX], g_ms[PROF_MAX];
+static long g_count[PROF_MAX];
+static hipEvent_t g_open[PROF_MAX];
 
-const char* prof_name(int cat) { return (cat >= 0 && cat < PROF_NCAT) ? kNames[cat] : "?"; }
+static std::string g_names[PROF_MAX];
+static int g_nnames = 0;
+
+int prof_register(const char* kernel_name) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (int i = 0; i < g_nnames; ++i) if (g_names[i] == kernel_name) return i;
+  if (g_nnames >= PROF_MAX) return PROF_MAX - 1;     // (cannot happen with the launch sites of this library: ~60 families)
+  g_names[g_nnames] = kernel_name;
+  return g_nnames++;
+}
+
+const char* prof_name(int cat) { return (cat >= 0 && cat < g_nnames) ? g_names[cat].c_str() : "?"; }
 bool prof_enabled() { return g_on; }
 
 static hipEvent_t get_event() {
@@ -92,19 +100,19 @@ int idxtts_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (on) {
     drain();
-    for (int c = 0; c < PROF_NCAT; ++c) { g_flops[c] = g_bytes[c] = g_ms[c] = 0.0; g_count[c] = 0; }
+    for (int c = 0; c < PROF_MAX; ++c) { g_flops[c] = g_bytes[c] = g_ms[c] = 0.0; g_count[c] = 0; }
   }
   g_on = on != 0;
   return 0;
 }
 
-int idxtts_profile_num_kernels(void) { return PROF_NCAT; }
+int idxtts_profile_num_kernels(void) { std::lock_guard<std::mutex> lk(g_mu); return g_nnames; }
 
 const char* idxtts_profile_kernel_name(int index) { return prof_name(index); }
 
 int idxtts_profile_read(int index, double* total_ms, double* flops, double* bytes, long* launches) {
   std::lock_guard<std::mutex> lk(g_mu);
-  if (index < 0 || index >= PROF_NCAT) return 1;
+  if (index < 0 || index >= g_nnames) return 1;
   drain();
   if (total_ms) *total_ms = g_ms[index];
   if (flops) *flops = g_flops[index];

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void rotary_qk_kernel(float* qkv, int M, int H
 int rotary_qk(float* qkv, int M, int H, int seq_len, const float* rope, hipStream_t st) {
   IDX_CHECK(qkv && rope && seq_len > 0, "rotary args");
   const size_t n = (size_t)M * 2 * H * 32;
-  ProfScope prof(PROF_ELTWISE, st, 0.0, 16.0 * n);
+  static const int cat = prof_register("rotary_qk_kernel");
+  ProfScope prof(cat, st, 0.0, 16.0 * n);
   hipLaunchKernelGGL(rotary_qk_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, qkv, M, H, seq_len, rope);
   IDX_LAUNCH_CHECK();
   return 0;
@@ -61,7 +62,8 @@ __global__ __launch_bounds__(256) void cfm_pack_kernel(const CfmPackArgs p) {
 
 int cfm_pack(const CfmPackArgs& a, hipStream_t st) {
   const double bytes = 4.0 * 2 * a.B * (double)a.T * (2 * a.C + a.D + a.S) * 2;
-  ProfScope prof(PROF_ELTWISE, st, 0.0, bytes);
+  static const int cat = prof_register("cfm_pack_kernel");
+  ProfScope prof(cat, st, 0.0, bytes);
   hipLaunchKernelGGL(cfm_pack_kernel, dim3(cdiv(a.T, 64), 2 * a.B), dim3(256), 0, st, a);
   IDX_LAUNCH_CHECK();
   return 0;
@@ -84,7 +86,8 @@ __global__ __launch_bounds__(256) void cfm_euler_kernel(const CfmEulerArgs p) {
 
 int cfm_euler(const CfmEulerArgs& a, hipStream_t st) {
   const size_t total = (size_t)a.B * a.C * a.T;
-  ProfScope prof(PROF_ELTWISE, st, 0.0, 16.0 * total);
+  static const int cat = prof_register("cfm_euler_kernel");
+  ProfScope prof(cat, st, 0.0, 16.0 * total);
   hipLaunchKernelGGL(cfm_euler_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, a);
   IDX_LAUNCH_CHECK();
   return 0;
@@ -104,7 +107,8 @@ __global__ __launch_bounds__(256) void gather_tail_rows_kernel(float* dst, int l
 int gather_tail_rows(float* dst, int ld_dst, const float* src, int ld_src, int cols, int N, int T, int t0, hipStream_t st) {
   IDX_CHECK(dst && src && t0 >= 0 && t0 < T && cols > 0, "gather_tail_rows args");
   const int Tn = T - t0;
-  ProfScope prof(PROF_ELTWISE, st, 0.0, 8.0 * N * (double)Tn * cols);
+  static const int cat = prof_register("gather_tail_rows_kernel");
+  ProfScope prof(cat, st, 0.0, 8.0 * N * (double)Tn * cols);
   hipLaunchKernelGGL(gather_tail_rows_kernel, dim3(Tn, N), dim3(256), 0, st, dst, ld_dst, src, ld_src, cols, T, t0, Tn);
   IDX_LAUNCH_CHECK();
   return 0;
@@ -174,7 +178,8 @@ __global__ __launch_bounds__(256) void gn_apply_mish_kernel(float* y, const floa
 
 int groupnorm1_mish(float* y, const float* x, const float* gamma, const float* beta, const int* row_len, int B, int T, int C,
                     float eps, float* stats, hipStream_t st) {
-  ProfScope prof(PROF_ELTWISE, st, 0.0, 12.0 * B * (double)T * C);
+  static const int cat = prof_register("gn_stats_kernel + gn_apply_mish_kernel");
+  ProfScope prof(cat, st, 0.0, 12.0 * B * (double)T * C);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(B), dim3(1024), 0, st, x, row_len, T, C, stats);
   hipLaunchKernelGGL(gn_apply_mish_kernel, dim3(B * T), dim3(256), 0, st, y, x, gamma, beta, row_len, stats, T, C, eps);
   IDX_LAUNCH_CHECK();

@@ -622,7 +622,12 @@ def make_gpt_ref():
     from transformers.cache_utils import DynamicCache
     NB, NEWB, SEED = 3, 24, 1234
     scorer_mod = _import_reference_beam_scorer()
-    for tag, stop_bias in (("a", 3.0), ("b", 5.5)):
+    # cases a / b: the reference's default warpers (temperature .8, top_k 30, top_p .8) -- on this tiny model they leave so few
+    # candidates that the sampled beams of b equal its deterministic ones.  Case c widens the nucleus (temperature 1.6, top_p .97)
+    # so that beam-sample really samples (asserted: c's sampled codes differ from its deterministic codes) while hypotheses still
+    # finish before the last step (asserted: a stop token before the final position).
+    cases = (("a", 3.0, 0.8, 30, 0.8), ("b", 5.5, 0.8, 30, 0.8), ("c", 4.0, 1.6, 30, 0.97))
+    for tag, stop_bias, temperature, top_k, top_p in cases:
         wb = dict(w)
         wb["mel_head.bias"] = w["mel_head.bias"].copy()
         wb["mel_head.bias"][cfg.stop_mel_token] += stop_bias
@@ -632,14 +637,14 @@ def make_gpt_ref():
             torch.manual_seed(SEED)
             with torch.no_grad(), quiet():
                 codes, _ = uvb.inference_speech(spk, text, emo, cond_lengths=ln_spk, emo_cond_lengths=ln_emo, emo_vec=emovec.expand(B, -1),
-                                                num_return_sequences=1, max_generate_length=NEWB, do_sample=do_sample, top_p=0.8, top_k=30,
-                                                temperature=0.8, length_penalty=0.0, num_beams=NB, repetition_penalty=10.0,
+                                                num_return_sequences=1, max_generate_length=NEWB, do_sample=do_sample, top_p=top_p, top_k=top_k,
+                                                temperature=temperature, length_penalty=0.0, num_beams=NB, repetition_penalty=10.0,
                                                 past_key_values=DynamicCache())
             # the same decode through the vendored loop + the reference's own BeamSearchScorer: THE expected value.  Where the
             # hypotheses finish early, transformers 5.x's rewritten beam search (no BeamScorer any more) stops by a different
             # rule than the vendored 4.x scorer; everywhere else the two agree, which checks the hand-driven loop.
             torch.manual_seed(SEED)
-            vend = drive_vendored_beam_search(uvb, scorer_mod, cfg, conds, text, NEWB, NB, do_sample, 0.8, 30, 0.8, 10.0, 0.0)
+            vend = drive_vendored_beam_search(uvb, scorer_mod, cfg, conds, text, NEWB, NB, do_sample, temperature, top_k, top_p, 10.0, 0.0)
             same = vend.shape == codes.shape and bool((vend == codes).all())
             print(f"beam {tag} {mode}: vendored-scorer drive {'==' if same else '!='} transformers-5.x generate;", vend.tolist())
             out[f"beam_{tag}_{mode}_codes"] = vend.numpy()
@@ -648,9 +653,16 @@ def make_gpt_ref():
             noise = torch.stack([torch.empty(B, NB * cfg.number_mel_codes).exponential_(1) for _ in range(NEWB)])
             if do_sample:
                 out[f"beam_{tag}_noise"] = noise.numpy()
-            chk = og.generate_beam(twb, cfg, conds, text, NEWB, noise, num_beams=NB, do_sample=do_sample)
+            chk = og.generate_beam(twb, cfg, conds, text, NEWB, noise, num_beams=NB, do_sample=do_sample, temperature=temperature, top_k=top_k,
+                                   top_p=top_p)
             assert chk.shape == vend.shape and bool((chk == vend).all()), "beam-search restatement != vendored beam search on the reference model"
         out[f"beam_{tag}_stop_bias"] = np.array(stop_bias, dtype=np.float32)
+        out[f"beam_{tag}_warpers"] = np.array([temperature, top_k, top_p], dtype=np.float64)
+    cs, cd = out["beam_c_sample_codes"], out["beam_c_det_codes"]
+    assert cs.shape != cd.shape or not np.array_equal(cs, cd), "case c must really sample"
+    early = [(row == cfg.stop_mel_token).any() and int(np.argmax(row == cfg.stop_mel_token)) < row.shape[0] - 1 for row in cs]
+    assert any(early), "case c must have a hypothesis that finishes early under sampling"
+    print("beam c: sampled != deterministic, rows finishing early under sampling:", early)
     np.savez_compressed(os.path.join(HERE, "gpt_ref.npz"), **out)
     print("wrote gpt_ref.npz", {k: v.shape for k, v in out.items()})
     return uv, cfg, w, out

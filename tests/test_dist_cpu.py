@@ -99,3 +99,67 @@ def test_bench_self_launch_command():
     assert "--nproc-per-node=8" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
     i = cmd.index(os.path.join(root, "bench.py"))
     assert cmd[i + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "1"]
+
+
+class _StubTTS:
+    """Stands in for IndexTTS2 on the CPU: the 'waveform' of an utterance encodes its tokens, so order and content can be checked."""
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.cfg = PipelineConfig.tiny()
+        self.calls = []
+
+    def synthesize_batch(self, toks, cond, max_mel_tokens=1500, noise=None, **kw):
+        stop = self.cfg.gpt.stop_text_token
+        self.calls.append(tuple(toks.shape))
+        out = []
+        for row in toks:
+            ids = row[row != stop]
+            n = int(ids.numel())
+            out.append((ids.float().sum() + cond.style.sum()).reshape(1, 1).expand(1, 20 + 3 * n).clone())
+        return out
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from indextts_amd.dist import ShardedSynthesizer
+    from indextts_amd.infer_v2 import PromptConditioning
+    cfg = PipelineConfig.tiny()
+    cond = PromptConditioning.synthetic(cfg, prompt_frames=11, tag="dist/prompt2")
+    g = torch.Generator().manual_seed(5)
+    ok, shapes_seen = True, []
+    for n in (7, 1, 0, 12):            # uneven shards, a single utterance (one rank idle), nothing at all, several batches per rank
+        lens = torch.randint(1, 9, (n,), generator=g).tolist()
+        texts = [torch.randint(2, 200, (L,), generator=g).tolist() for L in lens]
+        tts = _StubTTS()
+        sh = ShardedSynthesizer(tts, batch_size=4)
+        res = sh.synthesize(texts if rank == 0 else None, cond if rank == 0 else None, cond.shapes(), max_mel_tokens=16)
+        shapes_seen.append(tts.calls)
+        if rank == 0:
+            ok = ok and len(res) == n
+            for t, w in zip(texts, res):           # original order restored, each waveform from its own tokens
+                ok = ok and w.shape == (1, 20 + 3 * len(t)) and abs(float(w[0, 0]) - (sum(t) + float(cond.style.sum()))) < 1e-3
+        else:
+            ok = ok and res is None
+    q.put((rank, ok, shapes_seen))
+    dist.destroy_process_group()
+
+
+def test_synthesize_sharded_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in results] == [True, True]
+    # 7 utterances -> 4 + 3 (batches 4 | 3), 1 -> 1 + 0, 0 -> nothing, 12 -> 6 + 6 (batches 4, 2 each); sorted by length inside
+    r0, r1 = results[0][2], results[1][2]
+    assert [len(c) for c in r0] == [1, 1, 0, 2] and [len(c) for c in r1] == [1, 0, 0, 2]
+    assert [c[0] for c in r0[3]] == [4, 2] and r0[0][0][0] == 4 and r1[0][0][0] == 3

@@ -137,3 +137,87 @@ def test_config2_batch16_rows_equal_their_solo_runs(device, full):
             assert l1 <= 1e-3, l1
             assert (w1[0] - wavs[b]).abs().max().item() <= 32767 * 2e-3
     assert all(torch.isfinite(w).all() for w in wavs)
+
+
+def test_prompt_conditioning_at_production_size_vs_oracle(device):
+    """a8 at the real dimensions: conformer 6 x 512 (8 heads, 2048 units) + perceiver 32 x 1280 and the emotion pair (4 x 512 +
+    1 latent x 1024) on a T = 750 prompt (15 s of w2v-bert frames): the K = 261 632 split-K input projection, 375 frames of
+    rel-pos attention, against the CPU oracle."""
+    from indextts_amd.cond import ConditioningEncoders
+    from indextts_amd.config import GPTConfig
+    from oracle import cond as oc
+    cfg = GPTConfig()
+    w = weights.synth_gpt_cond_weights(cfg, tag="t/full/cond")
+    enc = ConditioningEncoders(w, cfg, device=device)
+    tw = {k: torch.from_numpy(v) for k, v in w.items()}
+    T = 750
+    x = torch.from_numpy(synth.uniform("t/full/cond/x", (1, T, 1024), 1.0))
+    lens = torch.tensor([T])
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        ref_lat = oc.get_conditioning(tw, cfg, x, lens)
+        ref_emo = oc.get_emovec(tw, cfg, x, lens)
+    lat = enc.get_conditioning(x.transpose(1, 2), lens).cpu()
+    ev = enc.get_emovec(x, lens).cpu()
+    assert lat.shape == ref_lat.shape == (1, 32, cfg.model_dim) and ev.shape == ref_emo.shape == (1, cfg.model_dim)
+    for got, want, name in ((lat, ref_lat, "conditioning latent"), (ev, ref_emo, "emotion vector")):
+        err = (got - want).abs()
+        scale = max(1.0, want.abs().max().item())
+        assert torch.isfinite(got).all() and err.max().item() <= 2e-4 * scale and err.mean().item() <= 2e-5 * scale, (name, err.max().item(), err.mean().item(), scale)
+
+
+def test_w2vbert_all_17_layers_at_15s_vs_oracle(device):
+    """f1 at production size: the 17 w2v-bert-2.0 layers `hidden_states[17]` needs, hidden 1024 / 16 heads / ffn 4096, one 15 s
+    prompt (T = 750 frames), against the CPU oracle (transformers' forward restated, oracle/semantic.py)."""
+    from indextts_amd.config import W2VBertConfig
+    from indextts_amd.semantic import SemanticModel
+    from oracle import semantic as osem
+    cfg = W2VBertConfig()
+    assert cfg.num_layers == 17
+    w = weights.synth_w2vbert_weights(cfg, tag="t/full/w2v")
+    sm = SemanticModel(w, cfg, device=device)
+    T = 750
+    feats = torch.from_numpy(synth.uniform("t/full/w2v/feats", (1, T, cfg.input_dim), 1.5))
+    mask = torch.ones(1, T, dtype=torch.long)
+    tw = {k: torch.from_numpy(v) for k, v in w.items()}
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        want = osem.get_emb(tw, cfg, feats, mask).numpy()
+    got = sm(feats, mask).cpu().numpy()
+    scale = max(1.0, np.abs(want).max())
+    err = np.abs(got - want)
+    assert np.isfinite(got).all() and err.max() <= 1e-3 * scale and err.mean() <= 1e-4 * scale, (err.max(), err.mean(), scale)
+
+
+def test_beam_search_at_full_size_16_utterances_vs_oracle(device, full):
+    """f2 at production size: 16 utterances x 3 beams = 48 decode rows on the full-size GPT (the B * num_beams <= 64 limit of
+    include/idxtts.h), deterministic beams and beam-sample with explicit Exp(1) draws, first 16 tokens against
+    oracle.gpt.generate_beam; a raised stop bias lets hypotheses finish inside the window."""
+    from indextts_amd.gpt import UnifiedVoice
+    from oracle import gpt as og
+    cfg, wg, ws, wv = full
+    g = cfg.gpt
+    wb = dict(wg)
+    wb["mel_head.bias"] = synth.uniform("t/full/beam/bias", (g.number_mel_codes,), 0.5).astype(np.float32)
+    wb["mel_head.bias"][g.stop_mel_token] = 8.5      # under sampling 5 of the 16 utterances finish inside the window (none deterministically)
+    uv = UnifiedVoice(wb, g, device=device)
+    c = _cond(cfg)
+    B, L, NEW, NB = 16, 12, 16, 3
+    text = torch.from_numpy(synth.integers("t/full/beam/text", (B, L), 2, g.number_text_tokens))
+    tw = {k: torch.from_numpy(v) for k, v in wb.items()}
+    conds = og.conds_latent(tw, g, c.spk_cond_latent.expand(B, -1, -1), c.emo_vec.expand(B, -1))
+    gen = torch.Generator().manual_seed(7)
+    noise = torch.stack([torch.empty(B, NB * g.number_mel_codes).exponential_(1, generator=gen) for _ in range(NEW)])
+    torch.set_num_threads(16)
+    for do_sample in (False, True):
+        with torch.no_grad():
+            want = og.generate_beam(tw, g, conds, text, NEW, noise, num_beams=NB, do_sample=do_sample)
+        codes, _ = uv.inference_speech(c.spk_cond_latent.expand(B, -1, -1), text, emo_vec=c.emo_vec.expand(B, -1), max_generate_length=NEW,
+                                       do_sample=do_sample, num_beams=NB, top_p=0.8, top_k=30, temperature=0.8, repetition_penalty=10.0,
+                                       length_penalty=0.0, exp_noise=noise)
+        got = codes.cpu().numpy()
+        assert got.shape == tuple(want.shape), (got.shape, tuple(want.shape))
+        mism = int((got != want.numpy()).any(axis=1).sum())
+        # exact-fp32 kernels vs torch CPU: summation order differs, so a near-tie between candidates may flip a row once in a while;
+        # at most one of the 16 utterances may differ, and every row must agree up to its first differing token's neighbourhood
+        assert mism <= 1, f"{mism} of {B} utterances differ (do_sample={do_sample})"

@@ -65,7 +65,7 @@ def test_latent_pass_vs_reference(ref, device):
     np.testing.assert_allclose(out.cpu().numpy(), g["latent"], rtol=0, atol=5e-5)
 
 
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
 @pytest.mark.parametrize("mode", ["det", "sample"])
 @pytest.mark.parametrize("graph", [False, True])
 def test_beam_search_vs_reference(ref, device, tag, mode, graph):
@@ -80,9 +80,10 @@ def test_beam_search_vs_reference(ref, device, tag, mode, graph):
     uv = UnifiedVoice(wb, cfg, device=device)
     noise = torch.from_numpy(g[f"beam_{tag}_noise"])
     want = g[f"beam_{tag}_{mode}_codes"]
+    temperature, top_k, top_p = (float(x) for x in g[f"beam_{tag}_warpers"])     # c: a wide nucleus, sampled beams != deterministic ones
     codes, _ = uv.inference_speech(torch.from_numpy(g["cond_latent"]), torch.from_numpy(g["text"]), emo_vec=torch.from_numpy(g["emovec_merged"]),
-                                   max_generate_length=noise.shape[0], do_sample=(mode == "sample"), num_beams=3, top_p=0.8, top_k=30,
-                                   temperature=0.8, repetition_penalty=10.0, length_penalty=0.0, exp_noise=noise, use_graph=graph)
+                                   max_generate_length=noise.shape[0], do_sample=(mode == "sample"), num_beams=3, top_p=top_p, top_k=int(top_k),
+                                   temperature=temperature, repetition_penalty=10.0, length_penalty=0.0, exp_noise=noise, use_graph=graph)
     np.testing.assert_array_equal(codes.cpu().numpy(), want)
 
 

@@ -94,17 +94,21 @@ def test_latent_pass_matches_reference_forward(ref):
     np.testing.assert_allclose(lat.numpy(), g["latent"], rtol=0, atol=5e-5)
 
 
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
 @pytest.mark.parametrize("mode", ["det", "sample"])
 def test_beam_search_matches_reference_inference_speech(ref, tag, mode):
     """num_beams=3 (the mode infer() runs by default, infer_v2.py:714-722): the reference's inference_speech under HF generate,
-    deterministic beams and beam-sample with the stored Exp(1) draws."""
+    deterministic beams and beam-sample with the stored Exp(1) draws.  Case c (temperature 1.6, top_p .97) is the one whose sampled
+    beams differ from its deterministic ones while hypotheses still finish early."""
     g, cfg, w, _, _ = ref
     w = dict(w)
     w["mel_head.bias"] = w["mel_head.bias"].clone()
     w["mel_head.bias"][cfg.stop_mel_token] += float(g[f"beam_{tag}_stop_bias"])
     want = g[f"beam_{tag}_{mode}_codes"]
     noise = torch.from_numpy(g[f"beam_{tag}_noise"])
+    temperature, top_k, top_p = (float(x) for x in g[f"beam_{tag}_warpers"])
     got = og.generate_beam(w, cfg, torch.from_numpy(g["conds"]), torch.from_numpy(g["text"]), noise.shape[0], noise,
-                           num_beams=3, do_sample=(mode == "sample"))
+                           num_beams=3, do_sample=(mode == "sample"), temperature=temperature, top_k=int(top_k), top_p=top_p)
     np.testing.assert_array_equal(got.numpy(), want)
+    if tag == "c" and mode == "sample":
+        assert not np.array_equal(want, g["beam_c_det_codes"]) and (want[:, :-1] == cfg.stop_mel_token).any()
