@@ -231,7 +231,8 @@ def build_pipeline(args, world, rank, dev):
     from indextts_amd.serving import BatchPipeline
     lanes = max(1, args.decode_lanes)
     pipe = None if args.no_overlap else BatchPipeline(tts, decode_lanes=lanes, acoustic_workers=max(1, args.acoustic_workers),
-                                                      exclusive=args.turns)
+                                                      coalesce=max(1, args.coalesce), lane_priority=args.lane_priority)
+    in_flight = lanes * max(1, args.coalesce) + 1     # batches submitted and not yet retired: every lane full plus one waiting
     if pipe is not None and args.trace_jobs:
         pipe.trace = []
     pending = []
@@ -246,7 +247,7 @@ def build_pipeline(args, world, rank, dev):
         return job.result()[0]
 
     def step_pipelined(last=False):
-        out = retire(pending.pop(0)) if len(pending) * per_step > lanes else None       # about lanes + 1 batches in flight
+        out = retire(pending.pop(0)) if len(pending) * per_step >= in_flight else None
         if sharder is not None:
             pending.append(sharder.begin(text_all.tolist() if rank == 0 else None, cond_dev if rank == 0 else None, shapes,
                                          max_mel_tokens=M, noise_fn=noise_rows))
@@ -308,8 +309,9 @@ def build_pipeline(args, world, rank, dev):
             "gpt_weights": args.gpt_weights,
             "batch_per_gpu": B, "text_tokens": L, "codes": M, "prompt_frames": Tp, "diffusion_steps": cfg.diffusion_steps}
     desc["step_overlap"] = ("none" if args.no_overlap else
-                            f"software pipeline across steps: {lanes} decode chain(s) of consecutive batches in flight (one stream + host thread "
-                            "each), one s2mel+vocoder stage at a time behind them on its own stream; every batch inside the timed region")
+                            f"software pipeline across steps: {lanes} decode chain(s) in flight (one stream + host thread each"
+                            + (f", a free lane decodes up to {args.coalesce} waiting 16-utterance requests as one batch" if args.coalesce > 1 else "")
+                            + f"), {max(1, args.acoustic_workers)} s2mel+vocoder stage(s) at a time behind them; every batch inside the timed region")
     step.flush = (lambda: None) if args.no_overlap else flush
     nref = 16 if world > 1 else len(text)        # multi-rank: a shard goes through the pipeline in batches of 16
     step.reference = lambda: tts.synthesize_batch(text[:nref], cond_dev, max_mel_tokens=M, noise=noise[:nref])[0]
@@ -425,8 +427,9 @@ def main() -> int:
     ap.add_argument("--decode-lanes", type=int, default=3,
                     help="pipeline workload: decode chains of consecutive batches in flight at once (each on its own stream and host thread)")
     ap.add_argument("--acoustic-workers", type=int, default=1, help="pipeline workload: s2mel + vocoder stages of different batches in flight at once")
-    ap.add_argument("--turns", action="store_true",
-                    help="pipeline workload: decode chains and acoustic stages take turns on the device instead of sharing it (measured equal)")
+    ap.add_argument("--lane-priority", default="high", choices=["high", "normal"], help="pipeline workload: HIP stream priority of the decode lanes")
+    ap.add_argument("--coalesce", type=int, default=1,
+                    help="pipeline workload: a free decode lane takes up to this many waiting 16-utterance requests and decodes them as one batch")
     ap.add_argument("--s2mel-overlap", action="store_true",
                     help="the CFM solver's two CFG halves on two streams (idxtts_s2mel_set_overlap): faster alone, slower beside decode lanes")
     ap.add_argument("--trace-jobs", action="store_true", help="pipeline workload: log the host-side start / end of every decode and acoustic job")
@@ -516,9 +519,9 @@ def main() -> int:
     assert torch.isfinite(out).all()
     log(f"[bench] rank {rank}: {args.steps} steps in {elapsed:.3f}s")
     if getattr(getattr(step, "pipe", None), "trace", None):
-        for kind, a, b in sorted(step.pipe.trace, key=lambda r: r[1]):
+        for kind, a, b, rows in sorted(step.pipe.trace, key=lambda r: r[1]):
             if b >= t_start:
-                log(f"[bench] job {kind:8s} start {a - t_start:8.3f} s  end {b - t_start:8.3f} s  ({b - a:.3f} s)")
+                log(f"[bench] job {kind:8s} {rows:3d} rows  start {a - t_start:8.3f} s  end {b - t_start:8.3f} s  ({b - a:.3f} s)")
     equal_seq = None
     if hasattr(step, "reference"):      # every step has the same inputs: each retired batch must equal the sequential call bit for bit
         ref = step.reference()

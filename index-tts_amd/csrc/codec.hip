@@ -166,16 +166,16 @@ int RepCodecModel::quantize(const float* x, int B, int T, long long* indices, fl
   float* nxt = w.xb;
   for (const ConvNeXtLayer& L : layers) {
     if (dwconv_ln(w.h, cur, L.dw_w, L.dw_b, L.ln_g, L.ln_b, B, T, D, 7, 1e-6f, st)) return 1;
-    if (lin(L.pw1, w.h, D, w.ff, F, M, st, ACT_GELU_ERF)) return 1;
-    if (lin(L.pw2, w.ff, F, nxt, D, M, st, ACT_NONE, cur, D)) return 1;
+    if (lin_exact(L.pw1, w.h, D, w.ff, F, M, st, ACT_GELU_ERF)) return 1;
+    if (lin_exact(L.pw2, w.ff, F, nxt, D, M, st, ACT_NONE, cur, D)) return 1;
     std::swap(cur, nxt);
   }
   if (ln(cur, w.h, fin_g, fin_b)) return 1;
-  if (lin(enc_out, w.h, D, w.enc, Hs, M, st)) return 1;
-  if (lin(in_proj, w.enc, Hs, w.ze, cd, M, st)) return 1;
+  if (lin_exact(enc_out, w.h, D, w.enc, Hs, M, st)) return 1;
+  if (lin_exact(in_proj, w.enc, Hs, w.ze, cd, M, st)) return 1;
   hipLaunchKernelGGL(nearest_code_kernel, dim3(M), dim3(256), 0, st, w.ze, codebook, codebook_n, cfg.codebook_size, cd, indices, w.zq);
   IDX_LAUNCH_CHECK();
-  return lin(out_proj, w.zq, cd, s_out, Hs, M, st);
+  return lin_exact(out_proj, w.zq, cd, s_out, Hs, M, st);
 }
 
 }  // namespace idxtts

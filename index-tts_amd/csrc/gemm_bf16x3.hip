@@ -57,7 +57,8 @@ bool gemm_bf16x3_uses_v2(const LinearWeights& w, const GemmArgs& a);
 int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w, const GemmArgs& a, hipStream_t stream, double flops,
                            double bytes);
 bool gemm_bf16x3_uses_v2(const LinearWeights& w, const GemmArgs& a) {
-  return w.wp16 && a.M >= 4096 && w.N >= 192 && w.K % 16 == 0 && (a.taps <= 1 || (w.K / a.taps) % 16 == 0);
+  // (M of a few hundred rows upwards: the 128 x 128 geometry of the LDS-DMA kernel takes what the 256 x 256 tiles would under-fill)
+  return w.wp16 && a.M >= 256 && w.N >= 96 && w.K % 16 == 0 && (a.taps <= 1 || (w.K / a.taps) % 16 == 0);
 }
 static size_t tiles_bytes(int N, int K) { return (size_t)cdiv(N, 128) * cdiv(K, 32) * WTILE_BYTES; }
 size_t linear_bf16x3_packed_bytes(int N, int K) { return tiles_bytes(N, K) + linear_planes_bytes(N, K); }

@@ -106,8 +106,12 @@ struct GemmV2P {
 #endif
 };
 
-// Workgroup = 4 x 2 waves, each a 64 x 128 output tile (2 x 4 MFMA tiles): 256 x 256 per workgroup, 512 threads, 32 KiB stages,
-// 4-deep ring, one workgroup per CU.
+// Two geometries of the same loop (CFG):
+//   0: workgroup = 4 x 2 waves, each a 64 x 128 output tile (2 x 4 MFMA tiles): 256 x 256 per workgroup, 512 threads, 32 KiB
+//      stages, 4-deep ring, one workgroup per CU -- launches with at least ~a round of 256-row tiles;
+//   1: workgroup = 2 x 2 waves, each 64 x 64 (2 x 2 MFMA tiles): 128 x 128 per workgroup, 256 threads, 16 KiB stages, two
+//      workgroups per CU -- launches whose 256 x 256 tiles would leave most CUs idle (M of a few hundred to a few thousand rows:
+//      one utterance's DiT, the prompt encoders' linears).  Same stage = 16 k, same four DMA pieces per wave and stage.
 //
 // Round 3: what a stage's instruction stream holds besides its 24 MFMAs decides the kernel (profiles/README.md "Round 3"):
 //   * every LDS-DMA is ONE buffer_load_dwordx4 ... lds: the lane's byte offset inside the operand planes is a VGPR computed
@@ -123,10 +127,13 @@ struct V2Rsrc { __amdgpu_buffer_rsrc_t a, b; };
 
 #define V2_WAITCNT(vm) __builtin_amdgcn_s_waitcnt(((vm) & 15) | (((vm) >> 4) << 14) | 0x70)   /* vmcnt(vm) lgkmcnt(0) */
 
-template <bool TAPS, int EPI>
+template <bool TAPS, int EPI, int CFG>
 __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, const int bn, const int tid) {
   constexpr int NSTAGE = 4;
-  constexpr int PLANE = 256 * 32;              // bytes of one operand plane of a stage (256 rows x 32 B)
+  constexpr int WMW = CFG ? 2 : 4, WNW = 2, TN = CFG ? 2 : 4;      // waves along M / N, 32-column MFMA tiles per wave
+  constexpr int BM = 64 * WMW, BN = 32 * TN * WNW;                 // 256 x 256 or 128 x 128
+  static_assert(BM / 32 == WMW * WNW && BN / 32 == WMW * WNW, "one 32-row block of A and of B per wave and plane");
+  constexpr int PLANE = BM * 32;               // bytes of one operand plane of a stage (BM = BN rows x 32 B)
   constexpr int STAGE_BYTES = 4 * PLANE;       // [A hi][A lo][B hi][B lo]
   constexpr int PPW = 4;                       // DMA instructions per wave and stage
   const GemmKP& p = q.g;
@@ -139,10 +146,10 @@ __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, con
   // ---- DMA role of this lane: row (lane >> 1) of the wave's 32-row block, LDS unit lane & 1, source unit swizzled ----
   const int lrow = lane >> 1;
   const int dunit = (lane & 1) ^ ((lrow >> 3) & 1);        // block bases are multiples of 32: row bit 3 = lrow bit 3
-  const int a_m = bm * 256 + 32 * wave + lrow;
+  const int a_m = bm * BM + 32 * wave + lrow;
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(q.a_hi), 0, q.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(q.b_hi), 0, q.b_bytes, 0x00020000);
-  const int voffB = (bn * 256 + 32 * wave + lrow) * 32 + dunit * 16;
+  const int voffB = (bn * BN + 32 * wave + lrow) * 32 + dunit * 16;
   int voffA = min(a_m, q.a_rows - 1) * 32 + dunit * 16;
   int seq_base = 0, seq_t = 0, seq_n = 0;
   if (TAPS) {
@@ -186,13 +193,13 @@ __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, con
   // fragment read offsets (bytes inside a plane image): row * 32 + (h ^ (row >> 3 & 1)) * 16, row = tile row of lane j
   const int sw = (h ^ ((j >> 3) & 1)) * 16;
   const int a_off = (wm * 64 + j) * 32 + sw;          // + t * 1024 for the second 32-row tile
-  const int b_offr = (wn * 128 + j) * 32 + sw;        // + t * 1024 per 32-column tile
+  const int b_offr = (wn * TN * 32 + j) * 32 + sw;    // + t * 1024 per 32-column tile
 
-  f32x16 acc[2][4];
+  f32x16 acc[2][TN];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
@@ -203,7 +210,7 @@ __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, con
       advance();
     }
 
-  struct Frag { bf16x8 ah[2], al[2], bh[4], bl[4]; };
+  struct Frag { bf16x8 ah[2], al[2], bh[TN], bl[TN]; };
   // stage s has landed for the whole workgroup: this wave's pieces by the counted wait (younger stages may stay in
   // flight), everyone's by the barrier; the lgkmcnt(0) retires this wave's fragment reads of stage s - 1, so after the
   // barrier that ring slot may be overwritten.  Stages in flight behind s: min(2, ns - 1 - s) (3 behind stage 0).
@@ -223,7 +230,7 @@ __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, con
       f.al[t] = *reinterpret_cast<const bf16x8*>(st + PLANE + a_off + t * 1024);
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < TN; ++t) {
       f.bh[t] = *reinterpret_cast<const bf16x8*>(st + 2 * PLANE + b_offr + t * 1024);
       f.bl[t] = *reinterpret_cast<const bf16x8*>(st + 3 * PLANE + b_offr + t * 1024);
     }
@@ -235,19 +242,20 @@ __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, con
     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);             \
     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], f.bl[nt], acc[mt][nt], 0, 0, 0);             \
     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
-    V2_MFMA3(0, 0) V2_MFMA3(0, 1)
+    // four MFMA groups (half a row of tiles each) with one DMA piece behind each
+    if constexpr (TN == 4) { V2_MFMA3(0, 0) V2_MFMA3(0, 1) } else { V2_MFMA3(0, 0) }
     __builtin_amdgcn_sched_barrier(0);
     if (more) issue_piece(0);
     __builtin_amdgcn_sched_barrier(0);
-    V2_MFMA3(0, 2) V2_MFMA3(0, 3)
+    if constexpr (TN == 4) { V2_MFMA3(0, 2) V2_MFMA3(0, 3) } else { V2_MFMA3(0, 1) }
     __builtin_amdgcn_sched_barrier(0);
     if (more) issue_piece(1);
     __builtin_amdgcn_sched_barrier(0);
-    V2_MFMA3(1, 0) V2_MFMA3(1, 1)
+    if constexpr (TN == 4) { V2_MFMA3(1, 0) V2_MFMA3(1, 1) } else { V2_MFMA3(1, 0) }
     __builtin_amdgcn_sched_barrier(0);
     if (more) issue_piece(2);
     __builtin_amdgcn_sched_barrier(0);
-    V2_MFMA3(1, 2) V2_MFMA3(1, 3)
+    if constexpr (TN == 4) { V2_MFMA3(1, 2) V2_MFMA3(1, 3) } else { V2_MFMA3(1, 1) }
     __builtin_amdgcn_sched_barrier(0);
     if (more) { issue_piece(3); advance(); }
     __builtin_amdgcn_sched_barrier(0);
@@ -295,7 +303,7 @@ __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, con
   }
   // (the last wait_stage left no DMA in flight; the epilogue synchronises the workgroup itself before it reuses the ring)
   V2_STAMP(2);
-  gemm_epilogue_wave<EPI>(p, acc, reinterpret_cast<float*>(smv2), bm * 256 + wm * 64, bn * 256 + wn * 128, wave, lane);
+  gemm_epilogue_wave<EPI, TN>(p, acc, reinterpret_cast<float*>(smv2), bm * BM + wm * 64, bn * BN + wn * TN * 32, wave, lane);
   V2_STAMP(6);
 #ifdef V2_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -304,15 +312,15 @@ __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, con
 }
 
 // one output tile per workgroup; XCD x owns the row tiles == x (mod 8) (gemm.hip explains the two walk orders)
-template <bool TAPS, int EPI>
-__global__ __launch_bounds__(512) void gemm_bf16x3_v2_kernel(const GemmV2P q) {
+template <bool TAPS, int EPI, int CFG>
+__global__ __launch_bounds__(CFG ? 256 : 512) void gemm_bf16x3_v2_kernel(const GemmV2P q) {
   const GemmKP& p = q.g;
   const int L = blockIdx.x, xcd = L & 7, qq = L >> 3;
   int bn, bm;
   if (p.n_fast) { const int bml = qq / p.nblocks; bn = qq - bml * p.nblocks; bm = bml * 8 + xcd; }
   else { bn = qq / p.mt8; bm = (qq - bn * p.mt8) * 8 + xcd; }
   if (bm >= p.mtiles) return;
-  gemm_v2_tile<TAPS, EPI>(q, bm, bn, threadIdx.x);
+  gemm_v2_tile<TAPS, EPI, CFG>(q, bm, bn, threadIdx.x);
 }
 
 // ---- per-stream scratch for the activation planes (grow-only) ----
@@ -356,12 +364,13 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
     IDX_CHECK(a.rope_T > 0 && a.rope_cols % 64 == 0 && a.act == ACT_NONE && (a.ldy & 3) == 0, "fused rotary arguments");
     q.g.rope = a.rope; q.g.rope_T = a.rope_T; q.g.rope_cols = a.rope_cols;
   }
-  // tile width 256 columns on one 8-wave workgroup per CU (the 128-column / two-workgroup form measured 1.5x slower on every
-  // hot-path shape, profiles/r01_gemm_bench.txt, and is gone)
-  constexpr int BN = 256;
-  q.g.mtiles = cdiv(a.M, 256);
+  // geometry: 256 x 256 tiles when they fill at least three quarters of a round of CUs, else 128 x 128 (four times as many tiles,
+  // two workgroups per CU)
+  const int cfg = ((int64_t)cdiv(a.M, 256) * cdiv(w.N, 256) >= 192) ? 0 : 1;
+  const int BMh = cfg ? 128 : 256, BNh = cfg ? 128 : 256;
+  q.g.mtiles = cdiv(a.M, BMh);
   q.g.mt8 = cdiv(q.g.mtiles, 8);
-  q.g.nblocks = cdiv(w.N, BN);
+  q.g.nblocks = cdiv(w.N, BNh);
   q.a_hi = hi; q.a_lo = lo; q.a_rows = a.M;
   q.npad = cdiv(w.N, 256) * 256;
   q.b_hi = static_cast<const __bf16*>(wplanes);
@@ -378,26 +387,30 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
   IDX_CHECK(grid < (1ll << 31), "grid size");
   static const int cat = prof_register("gemm_bf16x3_v2_kernel");
   ProfScope prof(cat, stream, flops, bytes);
-  constexpr int lds = 4 * (2 * 256 * 32 + 2 * 256 * 32);
+  const int lds = cfg ? 4 * (4 * 128 * 32) : 4 * (4 * 256 * 32);
   const bool paired = a.act == ACT_SWIGLU || a.act == ACT_GATE;
   IDX_CHECK(!(a.rope && (a.res || paired)), "the rotary epilogue takes no residual and no paired activation");
   IDX_CHECK(!a.row_len || a.seq_len >= 16, "row masks need seq_len >= 16");
   const int epi = a.rope ? EPI_ROPE : paired ? EPI_PAIRED : a.act != ACT_NONE ? EPI_ACT : EPI_PLAIN;
   typedef void (*KernelFn)(const GemmV2P);
-  static const KernelFn kernels[2][4] = {
-      {gemm_bf16x3_v2_kernel<false, EPI_PLAIN>, gemm_bf16x3_v2_kernel<false, EPI_ROPE>, gemm_bf16x3_v2_kernel<false, EPI_PAIRED>, gemm_bf16x3_v2_kernel<false, EPI_ACT>},
-      {gemm_bf16x3_v2_kernel<true, EPI_PLAIN>, gemm_bf16x3_v2_kernel<true, EPI_ROPE>, gemm_bf16x3_v2_kernel<true, EPI_PAIRED>, gemm_bf16x3_v2_kernel<true, EPI_ACT>}};
+  static const KernelFn kernels[2][2][4] = {
+      {{gemm_bf16x3_v2_kernel<false, EPI_PLAIN, 0>, gemm_bf16x3_v2_kernel<false, EPI_ROPE, 0>, gemm_bf16x3_v2_kernel<false, EPI_PAIRED, 0>, gemm_bf16x3_v2_kernel<false, EPI_ACT, 0>},
+       {gemm_bf16x3_v2_kernel<true, EPI_PLAIN, 0>, gemm_bf16x3_v2_kernel<true, EPI_ROPE, 0>, gemm_bf16x3_v2_kernel<true, EPI_PAIRED, 0>, gemm_bf16x3_v2_kernel<true, EPI_ACT, 0>}},
+      {{gemm_bf16x3_v2_kernel<false, EPI_PLAIN, 1>, gemm_bf16x3_v2_kernel<false, EPI_ROPE, 1>, gemm_bf16x3_v2_kernel<false, EPI_PAIRED, 1>, gemm_bf16x3_v2_kernel<false, EPI_ACT, 1>},
+       {gemm_bf16x3_v2_kernel<true, EPI_PLAIN, 1>, gemm_bf16x3_v2_kernel<true, EPI_ROPE, 1>, gemm_bf16x3_v2_kernel<true, EPI_PAIRED, 1>, gemm_bf16x3_v2_kernel<true, EPI_ACT, 1>}}};
   static std::once_flag attr_once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(attr_once, [&] {
-    for (int t = 0; t < 2; ++t)
-      for (int e = 0; e < 4; ++e) {
-        const hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[t][e]), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (r != hipSuccess) attr_err = r;
-      }
+    for (int c = 0; c < 2; ++c)
+      for (int t = 0; t < 2; ++t)
+        for (int e = 0; e < 4; ++e) {
+          const hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[c][t][e]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   c ? 4 * (4 * 128 * 32) : 4 * (4 * 256 * 32));
+          if (r != hipSuccess) attr_err = r;
+        }
   });
   IDX_HIP(attr_err);
-  hipLaunchKernelGGL(kernels[a.taps > 1 ? 1 : 0][epi], dim3((unsigned)grid), dim3(512), lds, stream, q);
+  hipLaunchKernelGGL(kernels[cfg][a.taps > 1 ? 1 : 0][epi], dim3((unsigned)grid), dim3(cfg ? 256 : 512), lds, stream, q);
   IDX_LAUNCH_CHECK();
   return 0;
 }

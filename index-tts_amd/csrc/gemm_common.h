@@ -135,16 +135,17 @@ __device__ __forceinline__ float act_apply_fast(float v, int act) {
 //   EPI_PAIRED  SwiGLU / tanh-sigmoid gate of packed [gate 32 | linear 32] column groups, residual, row mask
 //   EPI_ACT     any other activation (rolled loops, operands loaded in place: the rare shapes)
 // All waves of the workgroup must call it (one __syncthreads inside, behind the operand requests); `lds_base` = the workgroup's
-// LDS (>= 8 x 16 x 132 floats), no DMA in flight.
+// LDS (>= waves x 16 x (wave columns + 4) floats), no DMA in flight.
 enum { EPI_PLAIN = 0, EPI_ROPE = 1, EPI_PAIRED = 2, EPI_ACT = 3 };
 
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_wave(const GemmKP& p, f32x16 (&acc)[2][4], float* lds_base, const int row0, const int col0,
+template <int EPI, int TN>
+__device__ __forceinline__ void gemm_epilogue_wave(const GemmKP& p, f32x16 (&acc)[2][TN], float* lds_base, const int row0, const int col0,
                                                    const int wave, const int lane) {
+  constexpr int WC = 32 * TN;                   // packed columns of the wave's tile (128 or 64)
   constexpr bool PAIRED = EPI == EPI_PAIRED;
   constexpr bool PREF = EPI != EPI_ACT;         // residual / rotary rows prefetched into registers
-  constexpr int RS = 132;                       // floats per LDS row: 128 + 4 (row r + 1 starts one 16-byte slot further)
-  constexpr int LPR = PAIRED ? 16 : 32;         // lanes per row
+  constexpr int RS = WC + 4;                    // floats per LDS row: + 4 (row r + 1 starts one 16-byte slot further)
+  constexpr int LPR = PAIRED ? WC / 8 : WC / 4; // lanes per row
   constexpr int RPI = 64 / LPR;                 // rows per wave-instruction
   constexpr int NIT = 16 / RPI;                 // instructions per 16-row pass
   float* const lds = lds_base + wave * (16 * RS);
@@ -196,7 +197,7 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmKP& p, f32x16 (&acc
     const int mt = ps >> 1, hh = ps & 1;
     // accumulator rows of this pass: register r = (2 hh + q) * 4 + e is tile row 16 hh + 8 q + 4 h + e
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -251,7 +252,7 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmKP& p, f32x16 (&acc
     if (p.y_hi) {
       // plane order: 16-byte unit u of a chunk's 512-byte run = (row u >> 1, columns 8 (u & 1) ..); a chunk's lanes write 128
       // contiguous bytes per instruction
-      constexpr int CH = PAIRED ? 4 : 8;        // 16-column output chunks of this wave
+      constexpr int CH = PAIRED ? WC / 32 : WC / 16;     // 16-column output chunks of this wave
       constexpr int LPC = 64 / CH, NK = 32 / LPC;
       const int chunk = lane / LPC;
       const int n0 = (PAIRED ? (col0 >> 1) : col0) + chunk * 16;

@@ -1,5 +1,5 @@
 // Helpers shared by the small once-per-prompt models (cond.hip, semantic.hip): staged host tensors -> device weights in the
-// exact-fp32 MFMA GEMM pack, workspace carving, and the two launches every layer repeats.
+// exact-fp32 MFMA GEMM pack (+ the split-bf16 pack), workspace carving, and the two launches every layer repeats.
 #pragma once
 #include <cstring>
 #include <map>
@@ -46,6 +46,13 @@ int make_linear(DeviceArena& arena, const float* w, const float* bias, int N, in
   pack_linear(packed.data(), w, N, Kpad);
   if (up(arena, packed, &out->wp)) return 1;
   out->N = N; out->K = Kpad;
+  if (N >= 96 && Kpad % 16 == 0) {      // split-bf16 copy: launches of >= 256 rows run on the LDS-DMA kernel in GEMM_BF16X3 mode (gemm_forward)
+    std::vector<float> p16((linear_bf16x3_packed_bytes(N, Kpad) + 3) / 4);
+    pack_linear_bf16x3(p16.data(), w, N, Kpad);
+    const float* d16 = nullptr;
+    if (up(arena, p16, &d16)) return 1;
+    out->wp16 = d16;
+  }
   if (bias) {
     std::vector<float> b(bias, bias + N);
     if (up(arena, b, &out->bias)) return 1;
@@ -79,6 +86,16 @@ struct Carver {
 
 int lin(const LinearWeights& w, const float* x, int ldx, float* y, int ldy, int M, hipStream_t st, int act = ACT_NONE,
         const float* res = nullptr, int ldr = 0) {
+  GemmArgs g;
+  g.x = x; g.ldx = ldx; g.y = y; g.ldy = ldy; g.M = M; g.act = act; g.res = res; g.ldr = ldr;
+  // exact fp32 MFMA in GEMM_F32 mode; split-bf16 (3 bf16 MFMAs per product, ~2^-16 per product) for M >= 256 in the default mode
+  if ((act == ACT_GELU_ERF || act == ACT_RELU)) return gemm_tn_forward(w, g, st);      // (activations only the exact kernel's epilogue has)
+  return gemm_forward(w, g, st);
+}
+
+// exact fp32 whatever the mode: where an integer result follows (the semantic codec's nearest-code search)
+int lin_exact(const LinearWeights& w, const float* x, int ldx, float* y, int ldy, int M, hipStream_t st, int act = ACT_NONE,
+              const float* res = nullptr, int ldr = 0) {
   GemmArgs g;
   g.x = x; g.ldx = ldx; g.y = y; g.ldy = ldy; g.M = M; g.act = act; g.res = res; g.ldr = ldr;
   return gemm_tn_forward(w, g, st);

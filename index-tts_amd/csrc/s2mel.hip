@@ -580,17 +580,19 @@ static int half_streams_for(hipStream_t st, HalfStreams* out) {
   return 0;
 }
 
-// both halves of one estimator evaluation; `halves` = 2 (the solver) or 1 (the stand-alone entry point: conditional half only)
-static int dit_eval_halves(S2MelModel& m, CfmBuffers& w, int B, int T, int step, int halves, hipStream_t st) {
-  CfmBuffers v0 = half_view(m, w, 0, B, T);
-  if (halves == 1) return dit_eval(m, v0, B, T, step, st, nullptr);
-  CfmBuffers v1 = half_view(m, w, 1, B, T);
+// true: the two halves run as two chains on two streams (half_view buffers); false: ONE stacked evaluation of 2B sequences on the
+// caller's stream (larger launches: 394 instead of 2 x 198 tiles for an N = 512 GEMM fill the second round of CUs better)
+static bool halves_on_two_streams(hipStream_t st) {
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cap);
-  if (!g_s2mel_overlap || prof_enabled() || cap != hipStreamCaptureStatusNone) {     // per-launch event timing wants kernels alone
-    if (dit_eval(m, v0, B, T, step, st, nullptr)) return 1;
-    return dit_eval(m, v1, B, T, step, st, nullptr);
-  }
+  return g_s2mel_overlap && !prof_enabled() && cap == hipStreamCaptureStatusNone;     // (per-launch event timing wants kernels alone)
+}
+
+// one estimator evaluation of the solver: both CFG halves, on two streams (two_streams) or stacked
+static int dit_eval_halves(S2MelModel& m, CfmBuffers& w, int B, int T, int step, bool two_streams, hipStream_t st) {
+  if (!two_streams) return dit_eval(m, w, 2 * B, T, step, st, nullptr);
+  CfmBuffers v0 = half_view(m, w, 0, B, T);
+  CfmBuffers v1 = half_view(m, w, 1, B, T);
   HalfStreams hs;
   if (half_streams_for(st, &hs)) return 1;
   IDX_HIP(hipEventRecord(hs.fork, st));
@@ -642,15 +644,16 @@ int S2MelModel::cfm(const float* mu, const int* x_lens_host, const float* prompt
   if (gemm(wn_cond, w.t2, Wh, w.wnb, L * 2 * Wh, n_steps, st)) return 1;
   if (gemm(cond_proj, mu, cfg.content_dim, w.condp, D, B * T, st)) return 1;
   if (cfm_init_state(w.xstate, z, w.plen, B, C, T, st)) return 1;       // x[..., :prompt_len] = 0 (flow_matching.py:82)
+  const bool two_streams = halves_on_two_streams(st);
   for (int s = 0; s < n_steps; ++s) {
     CfmPackArgs pk;
     pk.x_in = w.x_in; pk.ld = 2 * C + D + cfg.style_dim; pk.x = w.xstate; pk.prompt = prompt; pk.prompt_len = w.plen;
     pk.cond = w.condp; pk.cond_null = cond_proj.bias; pk.style = style;
     pk.B = B; pk.T = T; pk.C = C; pk.D = D; pk.S = cfg.style_dim; pk.Tp_max = Tp_max;
     if (cfm_pack(pk, st)) return 1;
-    if (dit_eval_halves(*this, w, B, T, s, 2, st)) return 1;
-    CfmEulerArgs eu;
-    eu.x = w.xstate; eu.v = w.vout; eu.v_null = w.vout + (size_t)B * T * C; eu.ldv = C; eu.prompt_len = w.plen; eu.B = B; eu.T = T; eu.C = C; eu.dt = dt_host[s]; eu.cfg_rate = cfg_rate;
+    if (dit_eval_halves(*this, w, B, T, s, two_streams, st)) return 1;
+    CfmEulerArgs eu;      // (two streams: the null half's estimate lives in half_view's second block)
+    eu.x = w.xstate; eu.v = w.vout; eu.v_null = two_streams ? w.vout + (size_t)B * T * C : nullptr; eu.ldv = C; eu.prompt_len = w.plen; eu.B = B; eu.T = T; eu.C = C; eu.dt = dt_host[s]; eu.cfg_rate = cfg_rate;
     eu.v_t0 = w.tail_t0; eu.v_T = T - w.tail_t0;
     if (cfm_euler(eu, st)) return 1;
   }
@@ -689,7 +692,10 @@ int S2MelModel::estimator(const float* x, const float* prompt, const int* prompt
   pk.cond = w.condp; pk.cond_null = cond_proj.bias; pk.style = style;
   pk.B = B; pk.T = T; pk.C = C; pk.D = D; pk.S = cfg.style_dim; pk.Tp_max = Tp_max;
   if (cfm_pack(pk, st)) return 1;
-  if (dit_eval_halves(*this, w, B, T, 0, 1, st)) return 1;
+  {
+    CfmBuffers v0 = half_view(*this, w, 0, B, T);      // the conditional half alone
+    if (dit_eval(*this, v0, B, T, 0, st, nullptr)) return 1;
+  }
   IDX_HIP(hipMemcpyAsync(out_tm, w.vout, (size_t)B * T * C * sizeof(float), hipMemcpyDeviceToDevice, st));
   return 0;
 }

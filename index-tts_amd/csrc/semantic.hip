@@ -149,7 +149,7 @@ int W2VBertModel::forward(const float* feats, const int* lens_host, int B, int T
     if (lin(w1, w.h, D, w.ff, F, M, st, ACT_SILU)) return 1;
     GemmArgs a;
     a.x = w.ff; a.ldx = F; a.y = xout; a.ldy = D; a.M = M; a.res = xin; a.ldr = D; a.out_scale = 0.5f;      // hidden * 0.5 + residual
-    return gemm_tn_forward(w2, a, st);
+    return gemm_forward(w2, a, st);
   };
   for (const W2VLayer& L : layers) {
     if (half_ffn(L.ffn1_in, L.ffn1_out, L.ffn1_g, L.ffn1_b, x, y)) return 1;

@@ -3,19 +3,24 @@
 The reference synthesises one request after the other (infer_v2.py:732, serve_tars.py's single worker).  On an MI355X the two
 halves of a batch behave differently: the autoregressive decode (`IndexTTS2.gpt_stage`) is a chain of ~125 small dependent
 launches per token that leaves most CUs idle at any instant, s2mel + vocoder (`IndexTTS2.acoustic_stage`) are MFMA- / HBM-bound
-and fill the chip.  `BatchPipeline` keeps `decode_lanes` decode chains of consecutive batches running at once -- each on its own
-HIP stream, driven by its own host thread (the C call releases the GIL), with its own KV-cache workspace -- and runs their
-acoustic stages on `acoustic_workers` further streams.  Every batch is computed exactly as `synthesize_batch` computes it (same
-kernels, same order inside the batch): results are bit-identical, only the interleaving on the device changes.
+and fill the chip.  `BatchPipeline` keeps `decode_lanes` decode chains running at once -- each on its own HIP stream, driven by its
+own host thread (the C call releases the GIL), with its own KV-cache workspace -- and runs the acoustic stages on
+`acoustic_workers` further streams.
 
-Two schedules (measured on MI355X at configs[2], profiles/README.md "Round 3"):
-  * `exclusive=False` (default): decode chains and acoustic stages share the device.  A decode launch that needs 240-320
-    one-round workgroups waits for the 256x256-tile GEMMs of an acoustic stage to give CUs back (their workgroups own a CU's
-    whole register file), so the two kinds of work largely take turns anyway: 165-167 audio-s/s.
-  * `exclusive=True`: explicit turns.  Up to `decode_lanes` decode chains run together with nothing else on the device (1.18 s
-    for three chains of 512 tokens); when they have finished, their acoustic stages run (`acoustic_workers` at a time: stages of
-    different batches are at different kernels at any instant, so one stage's HBM-bound GEMM epilogues overlap another's
-    MFMA-bound main loops: 3 workers 163 audio-s/s, 1 worker 151); then the next group of decodes.  No better than sharing.
+`coalesce` > 1 is dynamic batching of the decode: a lane that becomes free takes up to `coalesce` waiting requests of the same
+prompt and text width and decodes them as ONE batch (a decode step streams the 965 MB of GPT weights once whatever the number of rows, so two
+16-utterance requests decoded together cost little more than one), then hands every request's rows to its own acoustic job.
+
+Every request is computed exactly as `synthesize_batch` computes it: the kernels treat the rows of a batch independently (same
+arithmetic and summation order per row whatever the batch size: tests/test_serving_gpu.py, and bench.py compares every retired
+batch with the sequential call bit for bit), so only the interleaving on the device changes.  (One caveat for merged decodes:
+which GEMM kernel a launch runs on depends on its row count -- split-bf16 from 256 rows up -- so a request of a few dozen GEMM rows
+could change kernels when merged; any real utterance is hundreds of rows on its own.)
+
+Measured at configs[2] (profiles/README.md "Round 3"): decode chains and acoustic stages SHARING the device give the same
+throughput as strict turns (3 decodes together, then their 3 acoustic stages: 163 vs 165 audio-s/s) -- a decode launch that needs
+240-320 one-round workgroups waits for the 256x256-tile GEMMs of an acoustic stage to give CUs back anyway (their workgroups own
+a CU's whole register file) -- so there is one schedule: sharing.
 
     pipe = BatchPipeline(tts, decode_lanes=3)
     futs = [pipe.submit(text_k, cond, max_mel_tokens=..., noise=noise_k) for text_k in batches]
@@ -24,6 +29,7 @@ Two schedules (measured on MI355X at configs[2], profiles/README.md "Round 3"):
 """
 from __future__ import annotations
 
+import collections
 import concurrent.futures
 import threading
 import time
@@ -32,81 +38,33 @@ from typing import Optional
 import torch
 
 
-class _Turns:
-    """Host-side turn taking between the two kinds of jobs.  A job calls enter(kind) before it touches the device and leave(kind)
-    once its stream has drained; `decode` jobs run together up to their limit, then every `acoustic` job they produced, then the
-    next group.  Purely a scheduling device: it never changes what a job computes."""
+class _Request:
+    __slots__ = ("text", "cond", "max_mel_tokens", "noise", "repetition_penalty", "sampling", "ready", "caller", "done")
 
-    def __init__(self, limits: dict):
-        self.limits = dict(limits)
-        self.cv = threading.Condition()
-        self.mode = "decode"
-        self.running = 0
-        self.started = 0                       # jobs started in the current turn
-        self.pending = {"decode": 0, "acoustic": 0}
-
-    def announce(self, kind: str) -> None:
-        with self.cv:
-            self.pending[kind] += 1
-            self._maybe_switch()
-            self.cv.notify_all()
-
-    def _maybe_switch(self) -> None:
-        if self.running:
-            return
-        other = "acoustic" if self.mode == "decode" else "decode"
-        if self.mode == "decode":
-            # hand over once this turn's decodes are done and have produced acoustic work; keep decoding while fewer than a
-            # full group have started and more decodes are waiting
-            if self.pending["acoustic"] and (self.started >= self.limits["decode"] or not self.pending["decode"]):
-                self.mode, self.started = other, 0
-            elif not self.pending["acoustic"]:
-                self.started = 0               # (a group whose decodes all failed leaves nothing to hand over)
-        elif not self.pending["acoustic"]:
-            self.mode, self.started = other, 0
-
-    def enter(self, kind: str) -> None:
-        with self.cv:
-            while True:
-                self._maybe_switch()
-                group_open = kind != "decode" or self.started < self.limits["decode"]
-                if self.mode == kind and self.running < self.limits[kind] and group_open:
-                    break
-                self.cv.wait(timeout=0.5)
-            self.running += 1
-            self.started += 1
-            self.pending[kind] -= 1
-
-    def cancel(self, kind: str) -> None:
-        """An announced job that will never enter (it failed first)."""
-        with self.cv:
-            self.pending[kind] -= 1
-            self._maybe_switch()
-            self.cv.notify_all()
-
-    def leave(self, kind: str) -> None:
-        with self.cv:
-            self.running -= 1
-            self._maybe_switch()
-            self.cv.notify_all()
+    def compatible(self, other: "_Request") -> bool:
+        # same prompt and settings, greedy (sampling draws are per call) and the SAME text width: a wider neighbour would left-pad this
+        # request's prompts further, which moves the key-tile boundaries of the prefill attention (a different fp32 summation order)
+        return (self.cond is other.cond and self.max_mel_tokens == other.max_mel_tokens and self.repetition_penalty == other.repetition_penalty
+                and self.sampling is None and other.sampling is None and int(self.text.shape[1]) == int(other.text.shape[1]))
 
 
 class BatchPipeline:
-    def __init__(self, tts, decode_lanes: int = 3, acoustic_workers: int = 1, exclusive: bool = False):
-        if decode_lanes < 1 or acoustic_workers < 1:
-            raise ValueError("decode_lanes and acoustic_workers must be >= 1")
+    def __init__(self, tts, decode_lanes: int = 3, acoustic_workers: int = 1, coalesce: int = 1, lane_priority: str = "high"):
+        if decode_lanes < 1 or acoustic_workers < 1 or coalesce < 1:
+            raise ValueError("decode_lanes, acoustic_workers and coalesce must be >= 1")
         self.tts = tts
         self.device = torch.device(tts.device)
         self.decode_lanes = decode_lanes
         self.acoustic_workers = acoustic_workers
-        self.exclusive = exclusive
+        self.coalesce = coalesce
         lo_pri, hi_pri = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
-        self._pri = {"decode": hi_pri, "acoustic": lo_pri}
+        self._pri = {"decode": hi_pri if lane_priority == "high" else lo_pri, "acoustic": lo_pri}
         self._tls = threading.local()          # one stream per worker THREAD: two jobs never share a stream (= a workspace)
         self._lanes = concurrent.futures.ThreadPoolExecutor(max_workers=decode_lanes, thread_name_prefix="idxtts-decode")
         self._acoustic = concurrent.futures.ThreadPoolExecutor(max_workers=acoustic_workers, thread_name_prefix="idxtts-acoustic")
-        self._turns = _Turns({"decode": decode_lanes, "acoustic": acoustic_workers}) if exclusive else None
-        self.trace = None                      # set to a list to record (kind, start, end) host times of every job (time.perf_counter)
+        self._queue = collections.deque()
+        self._qlock = threading.Lock()
+        self.trace = None                      # set to a list to record (kind, start, end, rows) host times of every job (time.perf_counter)
         tts.gpt.MAX_WORKSPACES = max(tts.gpt.MAX_WORKSPACES, decode_lanes + 2)
 
     def _stream(self, kind: str) -> torch.cuda.Stream:
@@ -120,76 +78,75 @@ class BatchPipeline:
         """Queue one batch; returns a Future of the list of waveforms `synthesize_batch` would return.  Inputs produced on the
         caller's current stream are safe to use (an event recorded here is waited for on the lane's stream), and the waveforms
         are safe to read on that stream (they are tied to it with record_stream before the Future resolves)."""
-        caller = torch.cuda.current_stream(self.device)
-        ready = torch.cuda.Event()
-        ready.record(caller)
-        done: concurrent.futures.Future = concurrent.futures.Future()
-        turns = self._turns
+        r = _Request()
+        r.text, r.cond, r.max_mel_tokens, r.noise = text_tokens, cond, max_mel_tokens, noise
+        r.repetition_penalty, r.sampling = repetition_penalty, sampling
+        r.caller = torch.cuda.current_stream(self.device)
+        r.ready = torch.cuda.Event()
+        r.ready.record(r.caller)
+        r.done = concurrent.futures.Future()
+        with self._qlock:
+            self._queue.append(r)
+        self._lanes.submit(self._lane_job)      # one drain per request: a drain that finds the queue empty (its request was merged) returns
+        return r.done
 
-        def acoustic_job(st):
-            entered = False
-            try:
-                torch.cuda.set_device(self.device)
-                if turns:
-                    turns.enter("acoustic")
-                entered = True
-                try:
-                    t0 = time.perf_counter()
-                    sa = self._stream("acoustic")
-                    with torch.cuda.stream(sa):
-                        wavs = self.tts.acoustic_stage(st, noise=noise)
-                        sa.synchronize()               # the state's tensors may be released once this returns
-                    if self.trace is not None:
-                        self.trace.append(("acoustic", t0, time.perf_counter()))
-                    for w in wavs:                      # allocated on the worker's stream, consumed on the caller's
-                        w.record_stream(caller)
-                finally:
-                    if turns:
-                        turns.leave("acoustic")
-                done.set_result(wavs)
-            except BaseException as e:                  # noqa: BLE001 -- handed to the caller through the future
-                if turns and not entered:
-                    turns.cancel("acoustic")
-                done.set_exception(e)
+    def _take(self):
+        with self._qlock:
+            if not self._queue:
+                return []
+            group = [self._queue.popleft()]
+            while len(group) < self.coalesce and self._queue and group[0].compatible(self._queue[0]):
+                group.append(self._queue.popleft())
+            return group
 
-        def lane_job():
-            entered = False
-            try:
-                torch.cuda.set_device(self.device)
-                if turns:
-                    turns.enter("decode")
-                entered = True
-                handed_over = False
-                try:
-                    t0 = time.perf_counter()
-                    sg = self._stream("decode")
-                    sg.wait_event(ready)
-                    with torch.cuda.stream(sg):
-                        st = self.tts.gpt_stage(text_tokens, cond, max_mel_tokens=max_mel_tokens, repetition_penalty=repetition_penalty,
-                                                sampling=sampling)
-                    # The lane waits for its own stream on the host (the decode has synchronised already, what is left is the
-                    # latent pass): a device-side event wait from the acoustic stream is not an option -- HIP refuses to wait on an
-                    # event whose stream is capturing, and this lane may be capturing the next batch's decode step by then.
-                    sg.synchronize()
-                    if self.trace is not None:
-                        self.trace.append(("decode", t0, time.perf_counter()))
-                    if turns:
-                        turns.announce("acoustic")
-                    handed_over = True
-                finally:
-                    if turns:
-                        turns.leave("decode")
-                if handed_over:
-                    self._acoustic.submit(acoustic_job, st)
-            except BaseException as e:                  # noqa: BLE001
-                if turns and not entered:
-                    turns.cancel("decode")
-                done.set_exception(e)
+    def _lane_job(self):
+        group = self._take()
+        if not group:
+            return
+        try:
+            torch.cuda.set_device(self.device)
+            t0 = time.perf_counter()
+            sg = self._stream("decode")
+            for r in group:
+                sg.wait_event(r.ready)
+            text = group[0].text if len(group) == 1 else torch.cat([torch.as_tensor(r.text).cpu() for r in group])      # equal widths
+            with torch.cuda.stream(sg):
+                st = self.tts.gpt_stage(text, group[0].cond, max_mel_tokens=group[0].max_mel_tokens,
+                                        repetition_penalty=group[0].repetition_penalty, sampling=group[0].sampling)
+            # The lane waits for its own stream on the host (the decode has synchronised already, what is left is the latent
+            # pass): a device-side event wait from the acoustic stream is not an option -- HIP refuses to wait on an event whose
+            # stream is capturing, and this lane may be capturing the next batch's decode step by then.
+            sg.synchronize()
+            if self.trace is not None:
+                self.trace.append(("decode", t0, time.perf_counter(), int(text.shape[0])))
+            a = 0
+            for r in group:                      # every request's rows go to its own acoustic job
+                b = a + int(r.text.shape[0])
+                n = max(st["code_lens"][a:b])
+                sub = {"cond": st["cond"], "B": b - a, "codes": st["codes"][a:b, :n].contiguous(), "code_lens": st["code_lens"][a:b],
+                       "code_lens_t": st["code_lens_t"][a:b].clone(), "latent": st["latent"][a:b, :n].contiguous(), "times": dict(st["times"])}
+                self._acoustic.submit(self._acoustic_job, r, sub)
+                a = b
+        except BaseException as e:                  # noqa: BLE001 -- handed to the callers through their futures
+            for r in group:
+                if not r.done.done():
+                    r.done.set_exception(e)
 
-        if turns:
-            turns.announce("decode")
-        self._lanes.submit(lane_job)
-        return done
+    def _acoustic_job(self, r: _Request, st: dict):
+        try:
+            torch.cuda.set_device(self.device)
+            t0 = time.perf_counter()
+            sa = self._stream("acoustic")
+            with torch.cuda.stream(sa):
+                wavs = self.tts.acoustic_stage(st, noise=r.noise)
+                sa.synchronize()                 # the state's tensors may be released once this returns
+            for w in wavs:                        # allocated on the worker's stream, consumed on the caller's
+                w.record_stream(r.caller)
+            if self.trace is not None:
+                self.trace.append(("acoustic", t0, time.perf_counter(), st["B"]))
+            r.done.set_result(wavs)
+        except BaseException as e:                  # noqa: BLE001
+            r.done.set_exception(e)
 
     def close(self):
         self._lanes.shutdown(wait=True)

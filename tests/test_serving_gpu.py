@@ -9,8 +9,11 @@ from indextts_amd.config import PipelineConfig
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("lanes", [1, 3])
-def test_batch_pipeline_equals_sequential(device, lanes):
+@pytest.mark.parametrize("lanes,coalesce,workers", [(1, 1, 1), (3, 1, 1), (2, 3, 2), (1, 4, 1)])
+def test_batch_pipeline_equals_sequential(device, lanes, coalesce, workers):
+    """coalesce > 1: a free lane decodes several waiting requests (different widths and row counts here) as ONE batch and hands each
+    request's rows to its own acoustic job -- the kernels treat rows independently, so every request still equals its own
+    sequential call bit for bit."""
     from indextts_amd.infer_v2 import IndexTTS2, PromptConditioning
     from indextts_amd.serving import BatchPipeline
     cfg = PipelineConfig.tiny()
@@ -23,17 +26,28 @@ def test_batch_pipeline_equals_sequential(device, lanes):
     cond = PromptConditioning.synthetic(cfg, prompt_frames=40, tag="t/serve/prompt").to(device)
     nb, M = 7, 20
     Tg = int(M * cfg.code_to_frame)
-    texts = [torch.from_numpy(synth.integers(f"t/serve/text{k}", (2 + k % 3, 9 + k), 2, cfg.gpt.number_text_tokens)) for k in range(nb)]
+    # widths 9, 9, 9, 10, 10, 11, 11: neighbours of equal width are what a coalescing lane merges (row counts differ)
+    texts = [torch.from_numpy(synth.integers(f"t/serve/text{k}", (2 + k % 3, 9 + (k + 1) // 3 + (k == 6)), 2, cfg.gpt.number_text_tokens)) for k in range(nb)]
     noises = [torch.from_numpy(synth.uniform(f"t/serve/noise{k}", (t.shape[0], cfg.s2mel.in_channels, 40 + Tg), 1.0)).to(device)
               for k, t in enumerate(texts)]
     import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        want = [tts.synthesize_batch(t, cond, max_mel_tokens=M, noise=n) for t, n in zip(texts, noises)]
-        torch.cuda.synchronize()
-        with BatchPipeline(tts, decode_lanes=lanes) as pipe:
-            futs = [pipe.submit(t, cond, max_mel_tokens=M, noise=n) for t, n in zip(texts, noises)]
-            got = [f.result() for f in futs]
+    from indextts_amd import _lib
+    # Merging requests changes the number of GEMM rows, and at this toy size that moves launches across the 256-row threshold
+    # between the exact-fp32 and the split-bf16 kernel (a real utterance is hundreds of rows on its own): the merged cases run in
+    # the exact mode, where kernel selection does not depend on the row count.
+    mode = _lib.get_gemm_mode()
+    if coalesce > 1:
+        _lib.set_gemm_mode(_lib.GEMM_F32)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = [tts.synthesize_batch(t, cond, max_mel_tokens=M, noise=n) for t, n in zip(texts, noises)]
+            torch.cuda.synchronize()
+            with BatchPipeline(tts, decode_lanes=lanes, coalesce=coalesce, acoustic_workers=workers) as pipe:
+                futs = [pipe.submit(t, cond, max_mel_tokens=M, noise=n) for t, n in zip(texts, noises)]
+                got = [f.result() for f in futs]
+    finally:
+        _lib.set_gemm_mode(mode)
     for k in range(nb):
         assert len(got[k]) == len(want[k])
         for a, b in zip(got[k], want[k]):

@@ -4,22 +4,19 @@
     python tools/make_traffic.py <fetch_size.json> <write_size.json> <out.json> [round]
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: the counters are in 1024-byte units and on gfx950 FETCH_SIZE
 reports half of a wide (16 B/lane) coalesced stream (MI355X_MICROARCH.md, HBM / rocprofv3 section).  Kernel symbols are
-folded into bench.py's profiler categories.
+folded into bench.py's kernel families (= kernel function names, csrc/prof.h).
 """
 import json
 import sys
 
-CATEGORY = [            # (substring of the kernel symbol, bench.py category)
-    ("gemv_fx_kernel", "gemv16_mfma"), ("gemm_bf16x3_v2_kernel", "gemm_bf16x3_256x256"), ("gemm_bf16x3_big_kernel<4>", "gemm_bf16x3_256x256"),
-    ("gemm_bf16x3_big_kernel<2>", "gemm_bf16x3_256x128"), ("gemm_bf16x3_kernel", "gemm_bf16x3_128x128"), ("gemm_tn_kernel", "gemm_tn_128x128"),
-    ("flash_attn", "flash_attn_f32"), ("decode_attn_kernel", "decode_attn"), ("conv1d_mfma_kernel<2, 2, 2, 2>", "conv1d_mfma_128x128"),
-    ("conv1d_bf16x3_kernel<2, 2, 2, 2>", "conv1d_mfma_128x128"), ("conv1d_bf16x3_kernel<3, 2, 1, 4>", "conv1d_mfma_96x256"),
-    ("conv1d_bf16x3_kernel<2, 2, 1, 4>", "conv1d_mfma_64x256"), ("conv1d_bf16x3_kernel<1, 4, 1, 4>", "conv1d_mfma_32x512"),
-    ("gemv_fx_combine_kernel", "gemv_combine"),
-    ("conv1d_mfma_kernel<3, 2, 1, 4>", "conv1d_mfma_96x256"), ("conv1d_mfma_kernel<2, 2, 1, 4>", "conv1d_mfma_64x256"),
-    ("conv1d_mfma_kernel<1, 4, 1, 4>", "conv1d_mfma_32x512"), ("aa_act_kernel", "aa_act"), ("rows_norm_kernel", "rows_norm"),
-    ("split_planes_kernel", "split_planes"), ("sample_greedy_kernel", "sample_greedy"),
-]
+# bench.py's kernel families are kernel function names (csrc/prof.h); families that keep their template arguments first
+FAMILIES = ["conv1d_bf16x3_kernel<2, 2, 2, 2>", "conv1d_bf16x3_kernel<3, 2, 1, 4>", "conv1d_bf16x3_kernel<2, 2, 1, 4>", "conv1d_bf16x3_kernel<1, 4, 1, 4>",
+            "conv1d_mfma_kernel<2, 2, 2, 2>", "conv1d_mfma_kernel<3, 2, 1, 4>", "conv1d_mfma_kernel<2, 2, 1, 4>", "conv1d_mfma_kernel<1, 4, 1, 4>",
+            "gemm_bf16x3_big_kernel<2>", "gemm_bf16x3_big_kernel<4>", "gemm_bf16x3_v2_kernel", "gemm_bf16x3_kernel", "gemm_tn_kernel",
+            "gemv_fx_combine_kernel", "gemv_fx_kernel", "decode_attn_kernel", "flash_attn_planes_kernel", "flash_attn_bf16x3_kernel",
+            "flash_attn_f32_kernel", "aa_act_kernel", "ada_rms_planes512_kernel", "rows_norm_kernel", "split_planes_kernel", "sample_greedy_kernel",
+            "conv_post_kernel", "cfm_pack_kernel", "embed_step_kernel"]
+CATEGORY = [(f, f) for f in FAMILIES]
 
 
 def fold(path, counter):
