@@ -303,7 +303,17 @@ __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, con
   }
   // (the last wait_stage left no DMA in flight; the epilogue synchronises the workgroup itself before it reuses the ring)
   V2_STAMP(2);
-  gemm_epilogue_wave<EPI, TN>(p, acc, reinterpret_cast<float*>(smv2), bm * BM + wm * 64, bn * BN + wn * TN * 32, wave, lane);
+  // 32 x 32 C/D layout: register r = (2 hh + qq) * 4 + e of tile (mt, nt) is row mt * 32 + 16 hh + 8 qq + 4 h + e, column nt * 32 + j
+  auto write_pass = [&](int ps, float* lds, int RS) {
+    const int mt = ps >> 1, hh = ps & 1;
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lds[(8 * qq + 4 * h + e) * RS + nt * 32 + j] = acc[mt][nt][(2 * hh + qq) * 4 + e];
+  };
+  gemm_epilogue_wave<EPI, TN>(p, write_pass, reinterpret_cast<float*>(smv2), bm * BM + wm * 64, bn * BN + wn * TN * 32, wave, lane);
   V2_STAMP(6);
 #ifdef V2_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -364,9 +374,11 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
     IDX_CHECK(a.rope_T > 0 && a.rope_cols % 64 == 0 && a.act == ACT_NONE && (a.ldy & 3) == 0, "fused rotary arguments");
     q.g.rope = a.rope; q.g.rope_T = a.rope_T; q.g.rope_cols = a.rope_cols;
   }
-  // geometry: 256 x 256 tiles when they fill at least three quarters of a round of CUs, else 128 x 128 (four times as many tiles,
-  // two workgroups per CU)
-  const int cfg = ((int64_t)cdiv(a.M, 256) * cdiv(w.N, 256) >= 192) ? 0 : 1;
+  // geometry (tools/gemm_ab.py, one process, interleaved): the 128 x 128 form is as fast as or faster than 256 x 256 tiles on every
+  // shape of the models here (M = 50 208: N = 512, K = 512 101 vs 117 us; N = 3072 448 vs 458; M = 10 848, N = 5120, K = 1280 401 vs
+  // 442; under-filled grids 1.7-2.6x) -- two workgroups per CU overlap one tile's store-bound epilogue with the other's main loop,
+  // and four times as many tiles quantise better over 256 CUs; only very large square products (8192^3: 337 vs 357 us) prefer 256.
+  const int cfg = ((int64_t)cdiv(a.M, 256) * cdiv(w.N, 256) >= 1024 && w.N >= 4096) ? 0 : 1;
   const int BMh = cfg ? 128 : 256, BNh = cfg ? 128 : 256;
   q.g.mtiles = cdiv(a.M, BMh);
   q.g.mt8 = cdiv(q.g.mtiles, 8);
@@ -393,11 +405,9 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
   IDX_CHECK(!a.row_len || a.seq_len >= 16, "row masks need seq_len >= 16");
   const int epi = a.rope ? EPI_ROPE : paired ? EPI_PAIRED : a.act != ACT_NONE ? EPI_ACT : EPI_PLAIN;
   typedef void (*KernelFn)(const GemmV2P);
-  static const KernelFn kernels[2][2][4] = {
-      {{gemm_bf16x3_v2_kernel<false, EPI_PLAIN, 0>, gemm_bf16x3_v2_kernel<false, EPI_ROPE, 0>, gemm_bf16x3_v2_kernel<false, EPI_PAIRED, 0>, gemm_bf16x3_v2_kernel<false, EPI_ACT, 0>},
-       {gemm_bf16x3_v2_kernel<true, EPI_PLAIN, 0>, gemm_bf16x3_v2_kernel<true, EPI_ROPE, 0>, gemm_bf16x3_v2_kernel<true, EPI_PAIRED, 0>, gemm_bf16x3_v2_kernel<true, EPI_ACT, 0>}},
-      {{gemm_bf16x3_v2_kernel<false, EPI_PLAIN, 1>, gemm_bf16x3_v2_kernel<false, EPI_ROPE, 1>, gemm_bf16x3_v2_kernel<false, EPI_PAIRED, 1>, gemm_bf16x3_v2_kernel<false, EPI_ACT, 1>},
-       {gemm_bf16x3_v2_kernel<true, EPI_PLAIN, 1>, gemm_bf16x3_v2_kernel<true, EPI_ROPE, 1>, gemm_bf16x3_v2_kernel<true, EPI_PAIRED, 1>, gemm_bf16x3_v2_kernel<true, EPI_ACT, 1>}}};
+#define V2_ROW(T, C) {gemm_bf16x3_v2_kernel<T, EPI_PLAIN, C>, gemm_bf16x3_v2_kernel<T, EPI_ROPE, C>, gemm_bf16x3_v2_kernel<T, EPI_PAIRED, C>, gemm_bf16x3_v2_kernel<T, EPI_ACT, C>}
+  static const KernelFn kernels[2][2][4] = {{V2_ROW(false, 0), V2_ROW(true, 0)}, {V2_ROW(false, 1), V2_ROW(true, 1)}};
+#undef V2_ROW
   static std::once_flag attr_once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(attr_once, [&] {

@@ -138,8 +138,10 @@ __device__ __forceinline__ float act_apply_fast(float v, int act) {
 // LDS (>= waves x 16 x (wave columns + 4) floats), no DMA in flight.
 enum { EPI_PLAIN = 0, EPI_ROPE = 1, EPI_PAIRED = 2, EPI_ACT = 3 };
 
-template <int EPI, int TN>
-__device__ __forceinline__ void gemm_epilogue_wave(const GemmKP& p, f32x16 (&acc)[2][TN], float* lds_base, const int row0, const int col0,
+// write_pass(ps, lds, RS): stores rows 16 ps .. 16 ps + 15 of the wave's accumulator tile into lds[row * RS + column] -- the one
+// place that knows the MFMA shape's C/D layout (32x32 or 16x16 tiles).
+template <int EPI, int TN, class WritePass>
+__device__ __forceinline__ void gemm_epilogue_wave(const GemmKP& p, WritePass&& write_pass, float* lds_base, const int row0, const int col0,
                                                    const int wave, const int lane) {
   constexpr int WC = 32 * TN;                   // packed columns of the wave's tile (128 or 64)
   constexpr bool PAIRED = EPI == EPI_PAIRED;
@@ -149,7 +151,6 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmKP& p, f32x16 (&acc
   constexpr int RPI = 64 / LPR;                 // rows per wave-instruction
   constexpr int NIT = 16 / RPI;                 // instructions per 16-row pass
   float* const lds = lds_base + wave * (16 * RS);
-  const int h = lane >> 5, j = lane & 31;
   const int sub = lane / LPR, c = lane % LPR;
   int n_out, nb0, nb1 = 0, lcol, ocol;          // output column, bias columns, LDS column read, LDS column of the finished value
   if (PAIRED) {
@@ -194,14 +195,7 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmKP& p, f32x16 (&acc
   const int nseq = p.row_len ? (p.M + p.seq_len - 1) / p.seq_len : 1;
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
-    const int mt = ps >> 1, hh = ps & 1;
-    // accumulator rows of this pass: register r = (2 hh + q) * 4 + e is tile row 16 hh + 8 q + 4 h + e
-#pragma unroll
-    for (int nt = 0; nt < TN; ++nt)
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) lds[(8 * q + 4 * h + e) * RS + nt * 32 + j] = acc[mt][nt][(2 * hh + q) * 4 + e];
+    write_pass(ps, lds, RS);
     // row mask of the pass: its 16 rows lie in at most two sequences (seq_len >= 16 is checked on the host)
     int t_first = 0, len_a = 0x7fffffff, len_b = 0x7fffffff, seq_len = 0x7fffffff;
     if (p.row_len) {

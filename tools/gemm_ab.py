@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""A/B of two builds of the LDS-DMA split-bf16 GEMM inside ONE process (interleaved rounds, per-launch HIP events of the
-library's own profiler, so the activation pre-pass is not in the number).  The `old` arm needs a library that still carries
-the previous kernel behind IDXTTS_V2_OLD=1 (a scratch build: csrc/zz_old_v2.hip; not part of the shipped sources).
+"""A/B/C of the LDS-DMA split-bf16 GEMM's geometries inside ONE process (interleaved rounds, per-launch HIP events of the library's
+own profiler, so the activation pre-pass is not in the number): 0 = 256 x 256 tiles (32x32x16 MFMA), 1 = 128 x 128 (32x32x16),
+2 = 128 x 128 on v_mfma_f32_16x16x32_bf16 (built, measured 3-10 % SLOWER than 1 on every large shape, removed again: profiles/README.md
+"Round 3").  Needs a scratch build whose gemm_bf16x3_v2_forward reads IDXTTS_EXP_V2_CFG (the shipped library picks the geometry by
+shape and reads no environment variable).
 
     python tools/gemm_ab.py [rounds] [iters]
 """
@@ -39,20 +41,21 @@ def run(M, N, K, act, with_res, rounds, iters):
     h = c_void_p()
     _lib.check(lib.idxtts_linear_create(_lib.ptr(w), _lib.ptr(b), N, K, 0, ctypes.byref(h)))
     st = _lib.current_stream()
-    outs, times = {}, {"old": [], "new": []}
+    ARMS = ("0", "1", "2")
+    outs, times = {}, {a: [] for a in ARMS}
 
     def call(y):
         _lib.check(lib.idxtts_linear_fwd(h, _lib.ptr(x), K, _lib.ptr(y), n_out, _lib.ptr(res) if with_res else None, n_out if with_res else 0, M, act, 1, st))
 
-    for arm in ("old", "new"):
-        os.environ["IDXTTS_V2_OLD"] = "1" if arm == "old" else "0"
+    for arm in ARMS:
+        os.environ["IDXTTS_EXP_V2_CFG"] = arm
         y = torch.full((M, n_out), float("nan"), device=dev)
         call(y)
         torch.cuda.synchronize()
         outs[arm] = y
     for _ in range(rounds):
-        for arm in ("old", "new"):
-            os.environ["IDXTTS_V2_OLD"] = "1" if arm == "old" else "0"
+        for arm in ARMS:
+            os.environ["IDXTTS_EXP_V2_CFG"] = arm
             y = outs[arm]
             call(y)
             torch.cuda.synchronize()
@@ -60,13 +63,13 @@ def run(M, N, K, act, with_res, rounds, iters):
             for _ in range(iters):
                 call(y)
             torch.cuda.synchronize()
-            ms, cnt = family_ms("gemm_bf16x3_256x256")
+            ms, cnt = family_ms("gemm_bf16x3_v2_kernel")
             lib.idxtts_profile_enable(0)
             times[arm].append(ms / max(cnt, 1))
-    os.environ["IDXTTS_V2_OLD"] = "0"
+    os.environ.pop("IDXTTS_EXP_V2_CFG", None)
     lib.idxtts_linear_destroy(h)
-    diff = (outs["old"] - outs["new"]).abs().max().item()
-    finite = bool(torch.isfinite(outs["new"]).all())
+    diff = max((outs["0"] - outs[a]).abs().max().item() for a in ARMS)
+    finite = all(bool(torch.isfinite(outs[a]).all()) for a in ARMS)
     ref = None
     if M * N * K <= 50208 * 512 * 512:
         yr = x.double() @ w.to(dev).double().t() + b.to(dev).double()
@@ -76,19 +79,18 @@ def run(M, N, K, act, with_res, rounds, iters):
             yr = (gte * torch.sigmoid(gte) * lin).reshape(M, N // 2)
         if with_res:
             yr = yr + res.double()
-        ref = (outs["new"].double() - yr).abs().max().item()
+        ref = max((outs[a].double() - yr).abs().max().item() for a in ARMS)
     med = {a: sorted(t)[len(t) // 2] for a, t in times.items()}
     fl = 2.0 * M * N * K
-    print(f"M={M:6d} N={N:5d} K={K:5d} act={act} res={int(with_res)}  old {med['old'] * 1e3:8.1f} us ({fl / med['old'] / 1e9:6.1f} TF-eq)  "
-          f"new {med['new'] * 1e3:8.1f} us ({fl / med['new'] / 1e9:6.1f} TF-eq)  ratio {med['new'] / med['old']:.3f}  "
-          f"max|old-new| {diff:.2e} finite={finite} max|new-fp64| {ref if ref is None else format(ref, '.2e')}", flush=True)
+    print(f"M={M:6d} N={N:5d} K={K:5d} act={act} res={int(with_res)}  " + "  ".join(f"cfg{a} {med[a] * 1e3:7.1f} us ({fl / med[a] / 1e9:5.1f} TF-eq)" for a in ARMS)
+          + f"  max|cfg0-cfgX| {diff:.2e} finite={finite} max|x-fp64| {ref if ref is None else format(ref, '.2e')}", flush=True)
 
 
 if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     shapes = [(50208, 512, 512, 0, True), (50208, 1536, 512, 0, False), (50208, 512, 1536, 0, True), (50208, 3072, 512, 3, False),
-              (28672, 512, 512, 0, True), (50208, 512, 1024, 0, False), (10848, 3840, 1280, 0, False), (10848, 5120, 1280, 1, False),
-              (10848, 1280, 5120, 0, True), (8192, 8192, 1024, 0, False), (5000, 200, 592, 0, True)]
+              (28672, 512, 512, 0, True), (10848, 3840, 1280, 0, False), (10848, 5120, 1280, 1, False), (2066, 1536, 512, 0, False),
+              (750, 1024, 1024, 0, True), (8192, 8192, 1024, 0, False), (5000, 200, 608, 0, True)]
     for (M, N, K, act, r) in shapes:
         run(M, N, K, act, r, rounds, iters)
