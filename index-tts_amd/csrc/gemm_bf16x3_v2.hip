@@ -84,11 +84,12 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 
 #ifdef V2_TIMING
 // Diagnostic build (tools/gemm_stamps.py; never the shipped library): s_memtime stamps of one wave per workgroup, written to a
-// buffer of their own: [workgroup][8] = start, first stage landed, end of the main loop, end of the epilogue, s_memrealtime x2.
+// buffer of their own: [workgroup][8] = start, first stage landed, end of the main loop, end of the epilogue (stores drained),
+// s_memrealtime x2, stores issued (wave 1 of the workgroup).
 static unsigned long long* g_v2_stamps = nullptr;
 extern "C" int idxtts_dbg_v2_stamps(void* buf) { g_v2_stamps = static_cast<unsigned long long*>(buf); return 0; }
-#define V2_STAMP(k) do { if (q.stamps && tid == 64 * 5) q.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define V2_RSTAMP(k) do { if (q.stamps && tid == 64 * 5) q.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define V2_STAMP(k) do { if (q.stamps && tid == 64) q.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define V2_RSTAMP(k) do { if (q.stamps && tid == 64) q.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define V2_STAMP(k)
 #define V2_RSTAMP(k)
@@ -107,11 +108,12 @@ struct GemmV2P {
 };
 
 // Two geometries of the same loop (CFG):
+//   1 (the one in use): workgroup = 2 x 2 waves, each 64 x 64 (2 x 2 MFMA tiles): 128 x 128 per workgroup, 256 threads, 16 KiB
+//      stages, 3-deep ring (48 KiB), <= 168 registers: THREE workgroups per CU, whose phases (main loop / store-bound epilogue)
+//      interleave on a CU; 4x the tiles of the large form, so launches of a few hundred rows still spread over the chip;
 //   0: workgroup = 4 x 2 waves, each a 64 x 128 output tile (2 x 4 MFMA tiles): 256 x 256 per workgroup, 512 threads, 32 KiB
-//      stages, 4-deep ring, one workgroup per CU -- launches with at least ~a round of 256-row tiles;
-//   1: workgroup = 2 x 2 waves, each 64 x 64 (2 x 2 MFMA tiles): 128 x 128 per workgroup, 256 threads, 16 KiB stages, two
-//      workgroups per CU -- launches whose 256 x 256 tiles would leave most CUs idle (M of a few hundred to a few thousand rows:
-//      one utterance's DiT, the prompt encoders' linears).  Same stage = 16 k, same four DMA pieces per wave and stage.
+//      stages, 4-deep ring, one workgroup per CU (round 2's geometry; measured slower on every shape, see the dispatch).
+//   Same stage = 16 k, same four DMA pieces per wave and stage in both.
 //
 // Round 3: what a stage's instruction stream holds besides its 24 MFMAs decides the kernel (profiles/README.md "Round 3"):
 //   * every LDS-DMA is ONE buffer_load_dwordx4 ... lds: the lane's byte offset inside the operand planes is a VGPR computed
@@ -129,7 +131,7 @@ struct V2Rsrc { __amdgpu_buffer_rsrc_t a, b; };
 
 template <bool TAPS, int EPI, int CFG>
 __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, const int bn, const int tid) {
-  constexpr int NSTAGE = 4;
+  constexpr int NSTAGE = CFG ? 3 : 4;      // ring depth (16-k stages): CFG 2 = the 128 x 128 geometry at three workgroups per CU
   constexpr int WMW = CFG ? 2 : 4, WNW = 2, TN = CFG ? 2 : 4;      // waves along M / N, 32-column MFMA tiles per wave
   constexpr int BM = 64 * WMW, BN = 32 * TN * WNW;                 // 256 x 256 or 128 x 128
   static_assert(BM / 32 == WMW * WNW && BN / 32 == WMW * WNW, "one 32-row block of A and of B per wave and plane");
@@ -171,11 +173,11 @@ __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, con
   const int sA = q.a_rows * 32, sB = q.npad * 32;          // bytes between two 16-k chunks of a plane
   const int cpt = TAPS ? (p.kc >> 4) : ns;                 // chunks per tap
   // scalar issue state: the next stage to request, its plane offsets, its chunk inside the tap
-  int ist = 0, soA = 0, soB = 0, ich = 0, itap = 0;
+  int ist = 0, soA = 0, soB = 0, ich = 0, itap = 0, wslot = 0, rslot = 0;      // (ring slots of the next stage to request / to read)
   if (TAPS) voffA = tap_voff(0);
   char* const lds_w = smv2 + wave * 1024;
   auto issue_piece = [&](int pi) {           // piece pi of stage ist: A hi, A lo, B hi, B lo
-    auto dst = (__attribute__((address_space(3))) void*)(lds_w + (ist & (NSTAGE - 1)) * STAGE_BYTES + pi * PLANE);
+    auto dst = (__attribute__((address_space(3))) void*)(lds_w + wslot * STAGE_BYTES + pi * PLANE);
     if (pi == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, dst, 16, voffA, soA, 0, 0);
     else if (pi == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, dst, 16, voffA, soA + q.a_plane, 0, 0);
     else if (pi == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, dst, 16, voffB, soB, 0, 0);
@@ -183,6 +185,7 @@ __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, con
   };
   auto advance = [&]() {
     ++ist;
+    wslot = wslot + 1 == NSTAGE ? 0 : wslot + 1;
     soB += sB;
     soA += sA;
     if (TAPS) {
@@ -215,15 +218,16 @@ __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, con
   // flight), everyone's by the barrier; the lgkmcnt(0) retires this wave's fragment reads of stage s - 1, so after the
   // barrier that ring slot may be overwritten.  Stages in flight behind s: min(2, ns - 1 - s) (3 behind stage 0).
   auto wait_stage = [&](int s) {
-    const int rem = ns - 1 - s;
-    if (rem >= 2) V2_WAITCNT(2 * PPW);
-    else if (rem == 1) V2_WAITCNT(PPW);
+    const int rem = ns - 1 - s;           // stages behind s; at most NSTAGE - 2 of them have been requested
+    if (NSTAGE >= 4 && rem >= 2) V2_WAITCNT(2 * PPW);
+    else if (NSTAGE >= 3 && rem >= 1) V2_WAITCNT(PPW);
     else V2_WAITCNT(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto load_frags = [&](Frag& f, int s) {
-    const char* st = smv2 + (s & (NSTAGE - 1)) * STAGE_BYTES;
+  auto load_frags = [&](Frag& f) {           // the next stage in order
+    const char* st = smv2 + rslot * STAGE_BYTES;
+    rslot = rslot + 1 == NSTAGE ? 0 : rslot + 1;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       f.ah[t] = *reinterpret_cast<const bf16x8*>(st + a_off + t * 1024);
@@ -266,37 +270,37 @@ __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, con
   Frag f0, f1;
   {   // stage 0: up to three younger stages in flight
     const int rem = ns - 1;
-    if (rem >= 3) V2_WAITCNT(3 * PPW);
-    else if (rem == 2) V2_WAITCNT(2 * PPW);
-    else if (rem == 1) V2_WAITCNT(PPW);
+    if (NSTAGE >= 4 && rem >= 3) V2_WAITCNT(3 * PPW);
+    else if (NSTAGE >= 3 && rem >= 2) V2_WAITCNT(2 * PPW);
+    else if (rem >= 1) V2_WAITCNT(PPW);
     else V2_WAITCNT(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
   V2_STAMP(1);
-  load_frags(f0, 0);
+  load_frags(f0);
   int i = 0;
   // steady state, straight-line: two younger stages in flight behind every wait, a stage to request beside every compute
   // (a branch-free body also keeps the compiler's counter model exact: at a join of paths with different numbers of LDS reads
   // pending it falls back to s_waitcnt lgkmcnt(0) in front of the first MFMA, i.e. behind the next stage's fragment reads)
-  for (; i + 5 < ns; i += 2) {
-    V2_WAITCNT(2 * PPW);
+  for (; i + NSTAGE + 1 < ns; i += 2) {
+    V2_WAITCNT((NSTAGE - 2) * PPW);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    load_frags(f1, i + 1);
+    load_frags(f1);
     compute(f0, true);
-    V2_WAITCNT(2 * PPW);
+    V2_WAITCNT((NSTAGE - 2) * PPW);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    load_frags(f0, i + 2);
+    load_frags(f0);
     compute(f1, true);
   }
   for (; i < ns; i += 2) {     // the last stages: the ring drains
-    if (i + 1 < ns) { wait_stage(i + 1); load_frags(f1, i + 1); }
+    if (i + 1 < ns) { wait_stage(i + 1); load_frags(f1); }
     else V2_WAITCNT(0);
     compute(f0, ist < ns);
     if (i + 1 < ns) {
-      if (i + 2 < ns) { wait_stage(i + 2); load_frags(f0, i + 2); }
+      if (i + 2 < ns) { wait_stage(i + 2); load_frags(f0); }
       else V2_WAITCNT(0);
       compute(f1, ist < ns);
     }
@@ -313,7 +317,7 @@ __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, con
 #pragma unroll
         for (int e = 0; e < 4; ++e) lds[(8 * qq + 4 * h + e) * RS + nt * 32 + j] = acc[mt][nt][(2 * hh + qq) * 4 + e];
   };
-  gemm_epilogue_wave<EPI, TN>(p, write_pass, reinterpret_cast<float*>(smv2), bm * BM + wm * 64, bn * BN + wn * TN * 32, wave, lane);
+  gemm_epilogue_wave<EPI, TN, 3>(p, write_pass, reinterpret_cast<float*>(smv2), bm * BM + wm * 64, bn * BN + wn * TN * 32, wave, lane);
   V2_STAMP(6);
 #ifdef V2_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -323,7 +327,7 @@ __device__ __forceinline__ void gemm_v2_tile(const GemmV2P& q, const int bm, con
 
 // one output tile per workgroup; XCD x owns the row tiles == x (mod 8) (gemm.hip explains the two walk orders)
 template <bool TAPS, int EPI, int CFG>
-__global__ __launch_bounds__(CFG ? 256 : 512) void gemm_bf16x3_v2_kernel(const GemmV2P q) {
+__global__ __launch_bounds__(CFG ? 256 : 512, CFG ? 3 : 2) void gemm_bf16x3_v2_kernel(const GemmV2P q) {
   const GemmKP& p = q.g;
   const int L = blockIdx.x, xcd = L & 7, qq = L >> 3;
   int bn, bm;
@@ -374,11 +378,12 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
     IDX_CHECK(a.rope_T > 0 && a.rope_cols % 64 == 0 && a.act == ACT_NONE && (a.ldy & 3) == 0, "fused rotary arguments");
     q.g.rope = a.rope; q.g.rope_T = a.rope_T; q.g.rope_cols = a.rope_cols;
   }
-  // geometry (tools/gemm_ab.py, one process, interleaved): the 128 x 128 form is as fast as or faster than 256 x 256 tiles on every
-  // shape of the models here (M = 50 208: N = 512, K = 512 101 vs 117 us; N = 3072 448 vs 458; M = 10 848, N = 5120, K = 1280 401 vs
-  // 442; under-filled grids 1.7-2.6x) -- two workgroups per CU overlap one tile's store-bound epilogue with the other's main loop,
-  // and four times as many tiles quantise better over 256 CUs; only very large square products (8192^3: 337 vs 357 us) prefer 256.
-  const int cfg = ((int64_t)cdiv(a.M, 256) * cdiv(w.N, 256) >= 1024 && w.N >= 4096) ? 0 : 1;
+  // geometry (tools/gemm_ab.py, one process, interleaved; profiles/README.md "Round 3"): 128 x 128 tiles, three workgroups per CU,
+  // beat the 256 x 256 form on every shape measured -- M = 50 208: N = 512, K = 512 99 vs 117 us, N = 1536 224 vs 252, N = 3072 (SwiGLU)
+  // 410 vs 456; M = 10 848, N = 5120, K = 1280 364 vs 435; 8192^2 x 1024 334 vs 347; under-filled grids (M = 750 .. 2066) 1.8-2.5x --
+  // three co-resident workgroups overlap one tile's store-bound epilogue with the others' main loops, and four times as many tiles
+  // quantise better over 256 CUs.  The 256 x 256 form stays in the source (CFG 0) as the measured alternative; nothing selects it.
+  const int cfg = 1;
   const int BMh = cfg ? 128 : 256, BNh = cfg ? 128 : 256;
   q.g.mtiles = cdiv(a.M, BMh);
   q.g.mt8 = cdiv(q.g.mtiles, 8);
@@ -399,7 +404,7 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
   IDX_CHECK(grid < (1ll << 31), "grid size");
   static const int cat = prof_register("gemm_bf16x3_v2_kernel");
   ProfScope prof(cat, stream, flops, bytes);
-  const int lds = cfg ? 4 * (4 * 128 * 32) : 4 * (4 * 256 * 32);
+  const int lds = cfg ? 3 * (4 * 128 * 32) : 4 * (4 * 256 * 32);
   const bool paired = a.act == ACT_SWIGLU || a.act == ACT_GATE;
   IDX_CHECK(!(a.rope && (a.res || paired)), "the rotary epilogue takes no residual and no paired activation");
   IDX_CHECK(!a.row_len || a.seq_len >= 16, "row masks need seq_len >= 16");
@@ -415,7 +420,7 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
       for (int t = 0; t < 2; ++t)
         for (int e = 0; e < 4; ++e) {
           const hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[c][t][e]), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   c ? 4 * (4 * 128 * 32) : 4 * (4 * 256 * 32));
+                                                   c ? 3 * (4 * 128 * 32) : 4 * (4 * 256 * 32));
           if (r != hipSuccess) attr_err = r;
         }
   });

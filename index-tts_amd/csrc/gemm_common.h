@@ -140,7 +140,7 @@ enum { EPI_PLAIN = 0, EPI_ROPE = 1, EPI_PAIRED = 2, EPI_ACT = 3 };
 
 // write_pass(ps, lds, RS): stores rows 16 ps .. 16 ps + 15 of the wave's accumulator tile into lds[row * RS + column] -- the one
 // place that knows the MFMA shape's C/D layout (32x32 or 16x16 tiles).
-template <int EPI, int TN, class WritePass>
+template <int EPI, int TN, int PF, class WritePass>      // PF: passes whose row operands are requested ahead (3, or 1 where registers are short)
 __device__ __forceinline__ void gemm_epilogue_wave(const GemmKP& p, WritePass&& write_pass, float* lds_base, const int row0, const int col0,
                                                    const int wave, const int lane) {
   constexpr int WC = 32 * TN;                   // packed columns of the wave's tile (128 or 64)
@@ -188,7 +188,10 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmKP& p, WritePass&& 
 #pragma unroll
     for (int it = 0; it < NIT; ++it) pre[ps][it] = fetch(row0 + ps * 16 + it * RPI + sub);
   };
-  if (PREF) { prefetch(0); prefetch(1); prefetch(2); }
+  if (PREF) {
+#pragma unroll
+    for (int ps = 0; ps < PF; ++ps) prefetch(ps);
+  }
   __syncthreads();                              // every wave has read its last fragments: the ring is free
   typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
   typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -266,7 +269,7 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmKP& p, WritePass&& 
         *reinterpret_cast<bf16x8_t*>(p.y_lo + o) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
       }
     }
-    if (PREF && ps == 0) prefetch(3);
+    if (PREF && ps + PF < 4) prefetch(ps + PF);
   }
 }
 

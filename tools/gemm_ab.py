@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """A/B/C of the LDS-DMA split-bf16 GEMM's geometries inside ONE process (interleaved rounds, per-launch HIP events of the library's
-own profiler, so the activation pre-pass is not in the number): 0 = 256 x 256 tiles (32x32x16 MFMA), 1 = 128 x 128 (32x32x16),
-2 = 128 x 128 on v_mfma_f32_16x16x32_bf16 (built, measured 3-10 % SLOWER than 1 on every large shape, removed again: profiles/README.md
-"Round 3").  Needs a scratch build whose gemm_bf16x3_v2_forward reads IDXTTS_EXP_V2_CFG (the shipped library picks the geometry by
+own profiler, so the activation pre-pass is not in the number): 0 = 256 x 256 tiles, one workgroup per CU; 1 = 128 x 128, three
+workgroups per CU (the shipped choice).  Also measured this way and removed again (profiles/README.md "Round 3"): 128 x 128 with a
+4-deep ring at two workgroups per CU (2-7 % slower than three), and 128 x 128 on v_mfma_f32_16x16x32_bf16 (3-10 % slower).  Needs a scratch build whose gemm_bf16x3_v2_forward reads IDXTTS_EXP_V2_CFG (the shipped library picks the geometry by
 shape and reads no environment variable).
 
     python tools/gemm_ab.py [rounds] [iters]
@@ -41,7 +41,7 @@ def run(M, N, K, act, with_res, rounds, iters):
     h = c_void_p()
     _lib.check(lib.idxtts_linear_create(_lib.ptr(w), _lib.ptr(b), N, K, 0, ctypes.byref(h)))
     st = _lib.current_stream()
-    ARMS = ("0", "1", "2")
+    ARMS = ("0", "1")
     outs, times = {}, {a: [] for a in ARMS}
 
     def call(y):

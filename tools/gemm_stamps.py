@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-kernel s_memtime stamps of the LDS-DMA GEMM (diagnostic build of the library: tools/build_timing_lib.sh ->
-tools/libidxtts_timing.so, gemm_bf16x3_v2.hip compiled with -DV2_TIMING).  Per workgroup (wave 5): cycles from start to the
+tools/libidxtts_timing.so, gemm_bf16x3_v2.hip compiled with -DV2_TIMING).  Per workgroup (wave 1): cycles from start to the
 first stage landed, main loop, epilogue (incl. store drain), and the in-kernel clock (s_memtime / s_memrealtime)."""
 import ctypes
 import os
@@ -27,7 +27,7 @@ def run(M, N, K, act, with_res):
     h = c_void_p()
     _lib.check(lib.idxtts_linear_create(_lib.ptr(w), None, N, K, 0, ctypes.byref(h)))
     st = _lib.current_stream()
-    grid = 8 * ((N + 255) // 256) * (((M + 255) // 256 + 7) // 8)
+    grid = 8 * ((N + 127) // 128) * (((M + 127) // 128 + 7) // 8)        # 128 x 128 tiles
     stamps = torch.zeros(grid * 8, dtype=torch.int64, device=dev)
 
     def call():
