@@ -102,6 +102,7 @@ struct GemmV2P {
   int a_rows, npad, nstages;
   int a_bytes, b_bytes;          // bytes of the hi + lo planes of each operand (buffer descriptors)
   int a_plane, b_plane;          // byte offset of the lo plane
+  int cs, nbg;                   // tile walk: column groups over the XCDs (1, 2, 4 or 8) and column blocks per group
 #ifdef V2_TIMING
   unsigned long long* stamps;
 #endif
@@ -331,8 +332,16 @@ __global__ __launch_bounds__(CFG ? 256 : 512, CFG ? 3 : 2) void gemm_bf16x3_v2_k
   const GemmKP& p = q.g;
   const int L = blockIdx.x, xcd = L & 7, qq = L >> 3;
   int bn, bm;
-  if (p.n_fast) { const int bml = qq / p.nblocks; bn = qq - bml * p.nblocks; bm = bml * 8 + xcd; }
-  else { bn = qq / p.mt8; bm = (qq - bn * p.mt8) * 8 + xcd; }
+  if (p.n_fast) {
+    // XCD x = (row class x / cs, column group x % cs): it owns the row tiles == its class (mod 8 / cs) and a contiguous 1 / cs of the
+    // column blocks, and walks its columns fastest.  cs = 1: every XCD sweeps all columns of its rows (A read once, the whole B through
+    // its L2); cs > 1 where B would not stay in a 4 MiB L2 next to the streaming A: the XCD's B slice stays resident, A is read cs times.
+    const int cs = q.cs, cg = xcd % cs, rc = xcd / cs;
+    const int bml = qq / q.nbg, bnl = qq - bml * q.nbg;
+    bm = bml * (8 / cs) + rc;
+    bn = cg * q.nbg + bnl;
+    if (bn >= p.nblocks) return;
+  } else { bn = qq / p.mt8; bm = (qq - bn * p.mt8) * 8 + xcd; }
   if (bm >= p.mtiles) return;
   gemm_v2_tile<TAPS, EPI, CFG>(q, bm, bn, threadIdx.x);
 }
@@ -400,7 +409,14 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
   IDX_CHECK(2 * plane < (1ull << 31) && 2 * b_plane < (1ull << 31), "operand planes beyond the 2 GiB a buffer offset addresses");
   q.a_plane = (int)plane; q.a_bytes = (int)(2 * plane);
   q.b_plane = (int)b_plane; q.b_bytes = (int)(2 * b_plane);
-  const int64_t grid = (int64_t)8 * q.g.nblocks * q.g.mt8;
+  // column groups: the smallest power of two that brings an XCD's B slice (hi + lo planes) under ~1.5 MB (in-process A/B,
+  // M = 50 208, K = 512: N = 1536 253 -> 235 us, N = 3072 449 -> 417 us; shapes with one group unchanged)
+  q.cs = 1;
+  if (q.g.n_fast) {
+    while (q.cs < 8 && (double)w.N * w.K * 4.0 / q.cs > 1.5e6 && q.g.nblocks >= 2 * q.cs) q.cs *= 2;
+  }
+  q.nbg = cdiv(q.g.nblocks, q.cs);
+  const int64_t grid = q.g.n_fast ? (int64_t)8 * q.nbg * cdiv(q.g.mtiles, 8 / q.cs) : (int64_t)8 * q.g.nblocks * q.g.mt8;
   IDX_CHECK(grid < (1ll << 31), "grid size");
   static const int cat = prof_register("gemm_bf16x3_v2_kernel");
   ProfScope prof(cat, stream, flops, bytes);
