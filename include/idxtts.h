@@ -122,8 +122,8 @@ int idxtts_get_gemm_mode(void);
 /* The CFM solver (idxtts_s2mel_cfm) can evaluate the conditional and the null half of its stacked batch (flow_matching.py:91-103,
  * one DiT.forward on 2B rows there) as two chains of launches on two streams, the null half a few kernels behind: same kernels
  * on the same rows, bit-identical results, 9 % less time for a solver that has the device to itself (one half's HBM-bound
- * epilogues beside the other's MFMA-bound loops).  on = 0 (default): both halves on the caller's stream, one after the other
- * (what per-launch profiling sees either way) -- serving loops with several decode chains in flight should leave it off. */
+ * epilogues beside the other's MFMA-bound loops).  on = 0 (default): one stacked 2B batch on the caller's stream, as the
+ * reference evaluates it -- serving loops with several decode chains in flight should leave it off (profiles/README.md "Round 3"). */
 int idxtts_s2mel_set_overlap(int on);
 int idxtts_s2mel_get_overlap(void);
 int idxtts_linear_destroy(idxtts_linear* lin);

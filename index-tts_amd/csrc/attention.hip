@@ -641,9 +641,6 @@ __global__ __launch_bounds__(256) void flash_attn_planes_kernel(const AttnPlanes
   long long tsave[5] = {tacc[0], tacc[1], tacc[2], tacc[3], tacc[4]};
   const long long t_loop = (long long)__builtin_readcyclecounter() - t_begin;
 #endif
-#if 0
-    printf("att wave %d tiles %d: wait+barrier %lld issue %lld qk %lld softmax %lld pv %lld | memtime %lld realtime(100MHz) %lld\n", wave, ntiles, tacc[0] / ntiles, tacc[1] / ntiles,
-#endif
 
   const float l_tot = xor32_sum(l_run);
   const float inv_l = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;

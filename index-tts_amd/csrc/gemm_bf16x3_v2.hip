@@ -21,6 +21,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <utility>
 
 #include "gemm_common.h"
 #include "prof.h"
@@ -348,7 +349,9 @@ __global__ __launch_bounds__(CFG ? 256 : 512, CFG ? 3 : 2) void gemm_bf16x3_v2_k
 
 // ---- per-stream scratch for the activation planes (grow-only) ----
 struct PlaneScratch { void* ptr = nullptr; size_t bytes = 0; };
-static std::map<hipStream_t, PlaneScratch> g_scratch;      // guarded by g_scratch_mu: stages of different batches may run on
+// keyed by (device, stream): the null stream exists on every device.  Guarded by g_scratch_mu (stages of different batches run on
+// different streams from different host threads).
+static std::map<std::pair<int, hipStream_t>, PlaneScratch> g_scratch;
 static std::mutex g_scratch_mu;
 
 
@@ -359,7 +362,9 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
   const int xk = a.taps > 1 ? w.K / a.taps : w.K;       // channels of the activation rows
   const size_t plane = (size_t)(xk / 16) * a.M * 16 * sizeof(__bf16);
   std::unique_lock<std::mutex> lock(g_scratch_mu);
-  PlaneScratch& sc = g_scratch[stream];      // (map nodes are stable: the reference outlives the lock; a stream has one user)
+  int dev_id = 0;
+  IDX_HIP(hipGetDevice(&dev_id));
+  PlaneScratch& sc = g_scratch[std::make_pair(dev_id, stream)];      // (map nodes are stable: the reference outlives the lock; a stream has one user)
   if (!a.x_planes && sc.bytes < 2 * plane) {
     IDX_HIP(hipStreamSynchronize(stream));
     if (sc.ptr) IDX_HIP(hipFree(sc.ptr));

@@ -308,7 +308,8 @@ def get_gemm_mode() -> int:
 
 
 def set_s2mel_overlap(on: bool) -> None:
-    """The CFM solver's two CFG halves on two streams (default) or one after the other on the caller's stream."""
+    """The CFM solver's two CFG halves on two streams (on) or as one stacked 2B batch on the caller's stream (off, the default: faster
+    beside concurrent decode chains, profiles/README.md "Round 3").  Same result bit for bit."""
     check(load().idxtts_s2mel_set_overlap(int(bool(on))))
 
 

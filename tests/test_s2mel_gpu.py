@@ -259,3 +259,37 @@ def test_cfm_long_prompts_tail_only_wavenet_vs_oracle(device, lens, plens):
         err = (out[b, :, :Lb] - ref[0]).abs()
         assert err.max().item() <= 3e-3 and err.mean().item() <= 1e-4, (b, err.max().item(), err.mean().item())
         assert (out[b, :, :Pb] == 0).all()
+
+
+def test_cfm_halves_on_two_streams_equal_the_stacked_batch(device):
+    """idxtts_s2mel_set_overlap(1): the conditional and unconditional halves of every CFM step on two streams instead of one stacked
+    2B batch (s2mel.hip::dit_eval_halves).  Rows of a batch are computed independently, so the mel must not change by one bit
+    (both forms keep every GEMM on the LDS-DMA kernel: B*T >= 256 rows)."""
+    import dataclasses
+    from indextts_amd import _lib
+    from indextts_amd.s2mel import S2Mel
+    cfg = dataclasses.replace(S2MelConfig.tiny(), hidden_dim=512, num_heads=8, depth=3, wn_hidden=512, wn_layers=2, block_size=1024)
+    w = weights.synth_s2mel_weights(cfg, tag="t/s2mel/chain")
+    sm = S2Mel(w, cfg, device=device, max_frames=1024)
+    lens, plens = [720, 655, 701], [60, 33, 48]
+    B, T, Tpm = 3, max(lens), max(plens)
+    z = torch.from_numpy(synth.uniform("t/s2mel/chain/z", (B, cfg.in_channels, T), 1.7))
+    mu = torch.from_numpy(synth.uniform("t/s2mel/chain/mu", (B, T, cfg.content_dim), 1.0))
+    prompt = torch.from_numpy(synth.uniform("t/s2mel/chain/prompt", (B, cfg.in_channels, Tpm), 1.0))
+    st = torch.from_numpy(synth.uniform("t/s2mel/chain/style", (B, cfg.style_dim), 1.0))
+    for b in range(B):
+        mu[b, lens[b]:] = 0
+    assert _lib.get_s2mel_overlap() == 0              # the shipped default
+    outs = {}
+    try:
+        for mode in (0, 1, 0):
+            _lib.set_s2mel_overlap(mode)
+            assert _lib.get_s2mel_overlap() == mode
+            o = sm.cfm_inference(mu, torch.LongTensor(lens), prompt, st, None, 3, inference_cfg_rate=0.7, z=z,
+                                 prompt_lens=torch.LongTensor(plens)).cpu()
+            assert torch.isfinite(o).all()
+            outs.setdefault(mode, []).append(o)
+    finally:
+        _lib.set_s2mel_overlap(0)
+    assert torch.equal(outs[0][0], outs[0][1])
+    assert torch.equal(outs[0][0], outs[1][0])
