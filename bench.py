@@ -126,7 +126,7 @@ def stage_rooflines(stages, prof, nprof, B, L, M, Tp, Tg, n_cfm, w_bytes_per_par
         dec_launches = sum(v["launches"] for k, v in prof.items() if k.startswith(DECODE_KERNELS)) / max(nprof, 1)
         out["gpt_decode"] = {"bound": "hbm", "alg_bytes_per_step": dec_bytes, "seconds": t, "achieved": round(dec_bytes / t / 1e9, 1), "peak": PEAK_HBM_GBS,
                              "unit": "GB/s", "frac": round(dec_bytes / t / 1e9 / PEAK_HBM_GBS, 4), "launches_per_token": round(dec_launches / M, 1),
-                             "us_per_token": round(1e6 * t / M, 1), "kv_cache": "fp32", "note": "gpt_gen_time includes the prefill (165 tokens, MFMA)"}
+                             "us_per_token": round(1e6 * t / M, 1), "kv_cache": "bf16" if kv_bytes == 2 else "fp32", "note": "gpt_gen_time includes the prefill (165 tokens, MFMA)"}
     T = Tp + Tg
     s2_flops = n_cfm * 2 * B * T * (148.4e6 + 26624.0 * T)
     t = stages.get("s2mel_time")
@@ -206,8 +206,9 @@ def build_pipeline(args, world, rank, dev):
     wv = weights.synth_bigvgan_weights(cfg.bigvgan, tag="bench/bigvgan")
     log(f"[bench] rank {rank}: synthetic weights in {time.time() - t0:.1f}s")
     compact = args.gpt_weights != "f32"
-    tts = IndexTTS2.from_state_dicts(cfg, wg, ws, wv, device=dev, gpt_weight_format=args.gpt_weights,
+    tts = IndexTTS2.from_state_dicts(cfg, wg, ws, wv, device=dev, gpt_weight_format=args.gpt_weights, gpt_kv_format=args.gpt_kv,
                                      keep_effective_gpt=compact and rank == 0 and not args.no_cpu_baseline)
+    kv16 = tts.gpt.kv_format == "bf16"
     if tts.gpt.effective_state_dict is not None:      # the CPU leg runs the SAME (rounded) model the kernels run
         wg = tts.gpt.effective_state_dict
     cond0 = PromptConditioning.synthetic(cfg, prompt_frames=Tp, tag="bench/prompt")
@@ -301,7 +302,7 @@ def build_pipeline(args, world, rank, dev):
             f"{cfg.diffusion_steps} CFM steps, {cores} threads ...")
         with torch.no_grad():
             c0 = time.perf_counter()
-            r = op.synthesize_one(twg, tws, wv, cfg, ctext, cond0, cnoise, Mc)
+            r = op.synthesize_one(twg, tws, wv, cfg, ctext, cond0, cnoise, Mc, kv_round=kv16)
             cdt = time.perf_counter() - c0
         caudio = r["wav"].shape[-1] / cfg.bigvgan.sampling_rate
         wavs, mid = tts.synthesize_batch(ctext, cond_dev, max_mel_tokens=Mc, noise=cnoise.to(dev), return_intermediates=True)
@@ -319,8 +320,9 @@ def build_pipeline(args, world, rank, dev):
     desc = {"workload": f"{'configs[4] (long-form, emotion vector, fp8 GPT weights, graph-replayed decode)' if args.longform else 'configs[2]'}: IndexTTS-2 full pipeline (gpt 472M + s2mel 98M + BigVGAN 112M params), batch {B} utterances per "
                         f"GPU, {L} text tokens, {M} codes ({Tg} mel frames, {audio_s / B:.2f} s) each, prompt {Tp} frames, "
                         f"{cfg.diffusion_steps} CFM steps cfg {cfg.cfg_rate}, greedy decode rep-penalty 10"
-                        + ("" if not compact else f", GPT linear weights stored as {args.gpt_weights} (rounded once at load; fp32 arithmetic)"),
-            "gpt_weights": args.gpt_weights,
+                        + ("" if not compact else f", GPT linear weights stored as {args.gpt_weights} (rounded once at load; fp32 arithmetic)")
+                        + ("" if not kv16 else ", KV cache stored as bf16 (keys / values rounded once when produced; fp32 arithmetic)"),
+            "gpt_weights": args.gpt_weights, "gpt_kv_cache": tts.gpt.kv_format,
             "batch_per_gpu": B, "text_tokens": L, "codes": M, "prompt_frames": Tp, "diffusion_steps": cfg.diffusion_steps}
     desc["step_overlap"] = ("none" if args.no_overlap else
                             f"software pipeline across steps: {lanes} decode chain(s) in flight (one stream + host thread each"
@@ -366,7 +368,7 @@ def build_prompt_or_infer(args, world, rank, dev):
     wc = weights.synth_repcodec_weights(ccfg, tag="bench/codec")
     for k in ("codebook.weight", "out_project.weight", "out_project.bias"):
         ws[f"semantic_codec.quantizer.quantizers.0.{k}"] = wc[f"quantizer.quantizers.0.{k}"]
-    tts = IndexTTS2.from_state_dicts(cfg, wg, ws, wv, device=dev, gpt_weight_format=args.gpt_weights)
+    tts = IndexTTS2.from_state_dicts(cfg, wg, ws, wv, device=dev, gpt_weight_format=args.gpt_weights, gpt_kv_format=args.gpt_kv)
     tts.prompt_encoders = PromptEncoders(weights.synth_w2vbert_weights(wcfg, tag="bench/w2v"), wc, weights.synth_campplus_weights(pcfg, tag="bench/campplus"),
                                          tts.s2mel, device=dev, w2vbert_cfg=wcfg, codec_cfg=ccfg, campplus_cfg=pcfg)
     log(f"[bench] synthetic weights + contexts in {time.time() - t0:.1f}s")
@@ -454,6 +456,10 @@ def main() -> int:
                     help="storage of the GPT linear weights: bf16 (default for the pipeline workload: what BASELINE configs[2] names), "
                          "fp8-e4m3 with a power-of-two scale per output channel (default for longform = configs[4]), or f32 (the reference's "
                          "own weights, bit for bit); arithmetic stays fp32; the CPU baseline / parity leg runs the same rounded model")
+    ap.add_argument("--gpt-kv", default=None, choices=["f32", "bf16"],
+                    help="storage of the GPT's KV cache: default bf16 with compact weights (the reference's use_fp16 halves weights and cache "
+                         "together), f32 with --gpt-weights f32; keys / values are rounded once when produced, arithmetic stays fp32, and the "
+                         "CPU baseline / parity leg rounds the same way")
     ap.add_argument("--gemm", default="bf16x3", choices=["bf16x3", "f32"],
                     help="arithmetic of the GEMM-shaped passes (s2mel, latent pass): split-bf16 (default) or exact fp32 MFMA")
     args = ap.parse_args()
@@ -574,7 +580,7 @@ def main() -> int:
         if stages and args.workload == "pipeline":
             wb = {"f32": 4, "bf16": 2, "fp8": 1}[args.gpt_weights]
             roofline_stages = stage_rooflines(stages, prof, nprof, desc["batch_per_gpu"], desc["text_tokens"], desc["codes"], desc["prompt_frames"],
-                                              int(desc["codes"] * 1.72), desc["diffusion_steps"], wb)
+                                              int(desc["codes"] * 1.72), desc["diffusion_steps"], wb, kv_bytes=2 if desc.get("gpt_kv_cache") == "bf16" else 4)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and cpu_leg is not None:
@@ -590,6 +596,8 @@ def main() -> int:
                      "(fp32 operands as hi+lo bf16, 3 bf16 MFMAs per product) GEMMs, DiT attention and convolutions in s2mel, the latent pass and the vocoder")
         if args.workload == "pipeline" and args.gpt_weights != "f32":
             dtype += f"; GPT linear weights STORED as {args.gpt_weights} (rounded once at load, widened to fp32 in registers)"
+        if args.workload in ("pipeline", "longform") and desc.get("gpt_kv_cache") == "bf16":
+            dtype += "; KV cache STORED as bf16 (rounded once when a key / value is produced, widened to fp32 in registers)"
         audio_total = audio_s_per_step_per_gpu * world * args.steps
         value = audio_total / elapsed
         cfgd = dict(desc)

@@ -167,6 +167,15 @@ int idxtts_gpt_create(const idxtts_gpt_config* cfg, idxtts_ctx** out);
  * (mathematically the same network up to Q) -- and prefill, latent pass and decode are all packed from them, so the three
  * passes run one model and idxtts_ctx_get_tensor returns exactly that model for the reference / oracle to run. */
 int idxtts_gpt_quantize_weights(idxtts_ctx* ctx, int format);
+/* Storage of the KV cache of the cached generation (idxtts_gpt_generate / _sampled / _beam): 0 = fp32 (default), 1 = bf16.
+ * The other half of the reference's reduced-precision switch: with `use_fp16` the whole GPT, its `past_key_values` included, is
+ * half precision (infer_v2.py:145-146; model_v2.py:149-151).  Here a key / value is rounded to bf16 (nearest even) once, when it
+ * is produced -- in the prefill (whose own attention then reads the rounded values) and in every decode step (the new token's own
+ * k / v included) -- and every product and sum stays fp32; the decode attention streams half the bytes (the KV read is the largest
+ * HBM stream of a batched decode step: 1.7 GB against 1.0 GB of bf16 weights at 16 utterances).  The latent pass has no cache and
+ * is unchanged.  Call any time between generations on the context; idxtts_gpt_workspace_bytes follows the format. */
+int idxtts_gpt_set_kv_format(idxtts_ctx* ctx, int format);
+int idxtts_gpt_get_kv_format(const idxtts_ctx* ctx);
 /* Greedy generations keep their instantiated decode-step hipGraph per (workspace address and size, B, prompt length, max_new_tokens,
  * penalty): the same shapes on the same workspace replay it without re-capturing (at most 8 are kept, least recently used first
  * out).  Returns how many are held (diagnostics / tests), -1 for a non-GPT context. */

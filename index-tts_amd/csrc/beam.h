@@ -30,7 +30,8 @@ struct BeamState {
   const DecodeState* st = nullptr;
   const float* exp_noise = nullptr;   // [steps][B][nb * V] Exp(1) draws (do_sample), or null: exp1_draw(seed, ...)
   unsigned long long seed = 0;
-  float* kcache = nullptr; float* vcache = nullptr;   // [L][R][H][16][Smax][4] / [L][R][H][Smax][64]
+  void* kcache = nullptr; void* vcache = nullptr;     // [L][R][H][G][Smax] / [L][R][H][Smax][G] 16-byte granules
+  int kv_gran = 16;                                   // G: granules per key (16 = fp32 cache, 8 = bf16 cache; decode.h)
   int B = 0, nb = 0, V = 0, stop_token = 0, L = 0, H = 0, Smax = 0, prompt_len = 0;   // prompt_len: KV positions shared by all beams (P + 1)
   int do_sample = 0, top_k = 0, early_stopping = 0;
   float penalty = 1.0f, temperature = 1.0f, top_p = 1.0f;

@@ -305,7 +305,8 @@ __global__ __launch_bounds__(1024) void beam_reorder_rows_kernel(const BeamState
   }
 }
 
-// KV rows of the generated positions [prompt_len, pos]: float4 granules, a thread moves one granule of all nb beams
+// KV rows of the generated positions [prompt_len, pos]: 16-byte granules (G per key: 16 in a fp32 cache, 8 in a bf16 one), a thread moves
+// one granule of all nb beams
 __global__ __launch_bounds__(256) void beam_reorder_kv_kernel(const BeamState p) {
   const int b = blockIdx.y, nb = p.nb;
   if (p.done[b]) return;
@@ -316,22 +317,24 @@ __global__ __launch_bounds__(256) void beam_reorder_kv_kernel(const BeamState p)
   const int pos = p.st->pos;                       // position written by this step's attention
   const int npos = pos - p.prompt_len + 1;
   if (npos <= 0) return;
-  const int R = p.B * nb, H = p.H, Smax = p.Smax;
-  const long items = (long)p.L * H * 16 * npos;
+  const int R = p.B * nb, H = p.H, Smax = p.Smax, G = p.kv_gran;
+  f32x4* const kc = static_cast<f32x4*>(p.kcache);
+  f32x4* const vc = static_cast<f32x4*>(p.vcache);
+  const long items = (long)p.L * H * G * npos;
   for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
-    const int lh = (int)(it / (16 * npos)), rem = (int)(it - (long)lh * 16 * npos);
+    const int lh = (int)(it / (G * npos)), rem = (int)(it - (long)lh * G * npos);
     const int l = lh / H, h = lh - l * H;
-    {   // K: [L][R][H][16][Smax][4]
+    {   // K: [L][R][H][G][Smax] granules
       const int c = rem / npos, s = p.prompt_len + (rem - c * npos);
       f32x4 v[BEAM_MAX];
-      for (int j = 0; j < nb; ++j) v[j] = *reinterpret_cast<const f32x4*>(p.kcache + ((((size_t)l * R + src[j]) * H + h) * 16 + c) * Smax * 4 + (size_t)s * 4);
-      for (int j = 0; j < nb; ++j) *reinterpret_cast<f32x4*>(p.kcache + ((((size_t)l * R + b * nb + j) * H + h) * 16 + c) * Smax * 4 + (size_t)s * 4) = v[j];
+      for (int j = 0; j < nb; ++j) v[j] = kc[((((size_t)l * R + src[j]) * H + h) * G + c) * Smax + s];
+      for (int j = 0; j < nb; ++j) kc[((((size_t)l * R + b * nb + j) * H + h) * G + c) * Smax + s] = v[j];
     }
-    {   // V: [L][R][H][Smax][64]
-      const int s = p.prompt_len + rem / 16, k = rem & 15;
+    {   // V: [L][R][H][Smax][G] granules
+      const int s = p.prompt_len + rem / G, k = rem - (rem / G) * G;
       f32x4 v[BEAM_MAX];
-      for (int j = 0; j < nb; ++j) v[j] = *reinterpret_cast<const f32x4*>(p.vcache + (((size_t)l * R + src[j]) * H + h) * Smax * 64 + (size_t)s * 64 + k * 4);
-      for (int j = 0; j < nb; ++j) *reinterpret_cast<f32x4*>(p.vcache + (((size_t)l * R + b * nb + j) * H + h) * Smax * 64 + (size_t)s * 64 + k * 4) = v[j];
+      for (int j = 0; j < nb; ++j) v[j] = vc[((((size_t)l * R + src[j]) * H + h) * Smax + s) * G + k];
+      for (int j = 0; j < nb; ++j) vc[((((size_t)l * R + b * nb + j) * H + h) * Smax + s) * G + k] = v[j];
     }
   }
 }

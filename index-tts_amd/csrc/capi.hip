@@ -328,6 +328,23 @@ int idxtts_gpt_quantize_weights(idxtts_ctx* ctx, int format) {
   API_END
 }
 
+int idxtts_gpt_set_kv_format(idxtts_ctx* ctx, int format) {
+  API_BEGIN
+  IDX_CHECK(ctx, "null ctx");
+  IDX_CHECK(format == 0 || format == 1, "KV cache format: 0 (fp32) or 1 (bf16)");
+  auto* m = dynamic_cast<GPTModel*>(ctx->model.get());
+  IDX_CHECK(m, "not a GPT context");
+  m->kv_fmt = format;      // cached decode graphs carry the format in their key; workspace sizes follow idxtts_gpt_workspace_bytes
+  return 0;
+  API_END
+}
+
+int idxtts_gpt_get_kv_format(const idxtts_ctx* ctx) {
+  if (!ctx) return -1;
+  auto* m = dynamic_cast<const GPTModel*>(ctx->model.get());
+  return m ? m->kv_fmt : -1;
+}
+
 int idxtts_gpt_graph_cache_entries(idxtts_ctx* ctx) {
   if (!ctx || !ctx->finalized) return -1;
   auto* m = dynamic_cast<GPTModel*>(ctx->model.get());

@@ -13,7 +13,9 @@ struct DecodeState {   // device-resident per-generation scalars (replay-friendl
 struct DecodeAttnArgs {
   const float* qkv_part = nullptr; int parts = 0; int part_rows = 0;   // [parts][part_rows][3d] c_attn split-K slab
   const float* qkv_bias = nullptr;                                      // [3d]
-  float* kcache = nullptr; float* vcache = nullptr;                     // this layer: [B][H][16][Smax][4] / [B][H][Smax][64]
+  // this layer's cache.  kv16 = 0: fp32, K [B][H][16][Smax][4], V [B][H][Smax][64].  kv16 = 1: bf16 (rounded to nearest even when a
+  // key / value is produced, the new token's own included), K [B][H][8][Smax][8], V [B][H][Smax][64]: 16-byte granules either way
+  void* kcache = nullptr; void* vcache = nullptr; int kv16 = 0;
   float* out = nullptr;                                                 // [B][d] as A-fragment images (frag_index)
   const int* kstart = nullptr;                                          // [B] first valid key (left pad), or null
   const DecodeState* st = nullptr;
@@ -77,7 +79,9 @@ struct SampleWarpArgs {
 int sample_warp_forward(const SampleWarpArgs& a, hipStream_t stream);
 
 int advance_state(DecodeState* st, hipStream_t stream);
-int kv_store_prefill(const float* qkv, float* kcache, float* vcache, int B, int H, int S, int Smax, int d, hipStream_t stream);
+// qkv [B][S][3d] -> caches, positions [0, S).  kv16: the caches hold bf16 and the k / v columns of qkv are rounded IN PLACE, so the
+// prefill attention that follows sees exactly the keys and values later steps read from the cache
+int kv_store_prefill(float* qkv, void* kcache, void* vcache, int kv16, int B, int H, int S, int Smax, int d, hipStream_t stream);
 constexpr int GATHER_MAX_TABLES = 5;
 struct GatherArgs {
   float* out = nullptr; int ld_out = 0; int d = 0;

@@ -13,6 +13,7 @@
 // KV cache layout (chosen for the decode read pattern, the only hot reader):
 //   K: [B][H][16][Smax][4]   dot products walk the keys with lanes = keys -> 16-byte, fully coalesced
 //   V: [B][H][Smax][64]      P.V walks the keys with lanes = head dim    -> 256-byte coalesced rows
+// or, with DecodeAttnArgs::kv16 (decode_attn16_kernel), the same in bf16: K [B][H][8][Smax][8], V [B][H][Smax][64].
 #include <algorithm>
 #include <cstdlib>
 
@@ -32,6 +33,53 @@ __device__ __forceinline__ float wave_add(float v) {
   return v;
 }
 
+// Output of one (utterance, head) workgroup: o = this thread's unnormalised output element (threads 0..63), mx / l = the piece's
+// score maximum and exp-sum.  NS == 1: normalise and write the A-fragment image for the c_proj GEMV.  Key split: leave (o, max, sum)
+// of this piece; the last piece to arrive merges all of them in piece order.
+__device__ __forceinline__ void decode_attn_finish(const DecodeAttnArgs& p, const int b, const int h, const int z, const int NS, const int tid,
+                                                   const float o, const float mx, const float l) {
+  const int d = p.d;
+  if (NS == 1) {
+    if (tid < 64) p.out[frag_index(b, h * 64 + tid, d >> 4)] = l > 0.f ? o / l : 0.f;     // A-fragment image for the c_proj GEMV
+    return;
+  }
+  // ---- key split: leave (o, max, sum) of this piece; the last piece to arrive merges all of them in piece order ----
+  __shared__ int s_last;
+  float* mine = p.part + ((size_t)(b * p.H + h) * NS + z) * 66;
+  if (tid < 64) __hip_atomic_store(&mine[tid], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 64) __hip_atomic_store(&mine[64], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 65) __hip_atomic_store(&mine[65], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // device-scope stores acknowledged before the arrival (see gemv_fx.hip)
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(&p.cnt[b * p.H + h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = old == (unsigned)NS - 1u;
+    if (s_last) __hip_atomic_store(&p.cnt[b * p.H + h], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last || tid >= 64) return;
+  const float* all = p.part + (size_t)(b * p.H + h) * NS * 66;
+  float mi[16], li[16], oi[16];       // every piece's (max, sum, this lane's output) in ONE round trip
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const bool on = i < NS;
+    mi[i] = on ? __hip_atomic_load(&all[i * 66 + 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1e30f;
+    li[i] = on ? __hip_atomic_load(&all[i * 66 + 65], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+    oi[i] = on ? __hip_atomic_load(&all[i * 66 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+  }
+  float M = -1e30f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) M = fmaxf(M, mi[i]);
+  float O = 0.f, L = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float wgt = li[i] > 0.f ? expf(mi[i] - M) : 0.f;
+    O += wgt * oi[i];
+    L += wgt * li[i];
+  }
+  p.out[frag_index(b, h * 64 + tid, d >> 4)] = L > 0.f ? O / L : 0.f;
+}
+
 // NT threads per workgroup: NT / 16 key groups in the P.V phase, NT keys per pass of the score phase.  512 threads at <= 128
 // VGPRs (two workgroups per CU) halve the number of dependent load -> use passes of the 256-thread form.
 template <int NT>
@@ -48,8 +96,8 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 1)) void decode_attn_kernel(co
   const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int pos = p.st->pos;                  // index of the token being processed = keys already cached
   const int d = p.d, Smax = p.Smax;
-  float* kc = p.kcache + (size_t)(b * p.H + h) * 16 * Smax * 4;
-  float* vc = p.vcache + (size_t)(b * p.H + h) * Smax * 64;
+  float* kc = static_cast<float*>(p.kcache) + (size_t)(b * p.H + h) * 16 * Smax * 4;
+  float* vc = static_cast<float*>(p.vcache) + (size_t)(b * p.H + h) * Smax * 64;
 
   // Everything that does not depend on the new token's q is put in flight first: this thread's first key (16 x 16 B,
   // coalesced across threads) and its first 8 value rows of the P.V phase; the kernel is a chain of dependent
@@ -177,49 +225,188 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 1)) void decode_attn_kernel(co
 #pragma unroll
     for (int g = 0; g < NG; ++g) o += outp[g * 64 + tid];
   }
-  if (NS == 1) {
-    if (tid < 64) p.out[frag_index(b, h * 64 + tid, d >> 4)] = l > 0.f ? o / l : 0.f;     // A-fragment image for the c_proj GEMV
-    return;
+  decode_attn_finish(p, b, h, z, NS, tid, o, mx, l);
+}
+
+// ---- bf16 cache form (DecodeAttnArgs::kv16) ----
+// Same structure, half the bytes: K [B][H][8][Smax][8] bf16 (a key's 16-byte granule per 8-dim chunk: 8 coalesced 16-byte loads per
+// key instead of 16), V [B][H][Smax][64] bf16 (128-byte rows: 8 lanes x 16 bytes per key, 64 key groups per workgroup).  A key /
+// value is rounded to bf16 (nearest even) when it is produced -- the new token's own k / v too, so a position reads the same
+// whether it is the newest or an old one -- and widened exactly (<< 16) when used; every product and sum is fp32.
+__device__ __forceinline__ unsigned bf16_rne_bits(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ float bf16_round_f32(float f) { return __uint_as_float(bf16_rne_bits(f) << 16); }
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NT>
+__global__ __launch_bounds__(NT, (NT == 512 ? 4 : 1)) void decode_attn16_kernel(const DecodeAttnArgs p) {
+  constexpr int NW = NT / 64, NG = NT / 8;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* qs = sm;            // [64] scaled query
+  float* knew = sm + 64;     // [64] (rounded)
+  float* vnew = sm + 128;    // [64] (rounded)
+  float* red = sm + 192;     // [2 * NW]
+  float* outp = sm + 256;    // [NG][64] per-key-group partial outputs
+  float* pr = sm + 256 + NG * 64;   // [Smax] scores / probabilities
+
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int pos = p.st->pos;
+  const int d = p.d, Smax = p.Smax;
+  u32x4* const kc = static_cast<u32x4*>(p.kcache) + (size_t)(b * p.H + h) * 8 * Smax;      // granule (c, s) at c * Smax + s
+  u32x4* const vc = static_cast<u32x4*>(p.vcache) + (size_t)(b * p.H + h) * Smax * 8;      // granule (s, c) at s * 8 + c
+
+  const int ks0 = p.kstart ? p.kstart[b] : 0;
+  const int NS = gridDim.z, z = blockIdx.z;
+  const int chunk = NS > 1 ? (((pos - ks0 + NS) / NS + 15) & ~15) : pos - ks0 + 1;
+  const int ks = ks0 + z * chunk;
+  const int ke = min(pos, ks + chunk - 1);          // inclusive; ks > ke: an empty piece
+  const int grp = tid >> 3, l8 = tid & 7;
+  const int s_first = ks + tid;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  u32x4 kk0[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) kk0[i] = (s_first < pos && s_first <= ke) ? kc[(size_t)i * Smax + s_first] : zero4;
+  constexpr int VP = 2;      // value rows prefetched per lane before the scores (NG * VP = 128 keys, as in the fp32 form)
+  u32x4 vpre[VP];
+#pragma unroll
+  for (int j = 0; j < VP; ++j) {
+    const int sj = ks + grp + NG * j;
+    vpre[j] = (sj < pos && sj <= ke) ? vc[(size_t)sj * 8 + l8] : zero4;
   }
-  // ---- key split: leave (o, max, sum) of this piece; the last piece to arrive merges all of them in piece order ----
-  __shared__ int s_last;
-  float* mine = p.part + ((size_t)(b * p.H + h) * NS + z) * 66;
-  if (tid < 64) __hip_atomic_store(&mine[tid], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (tid == 64) __hip_atomic_store(&mine[64], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (tid == 65) __hip_atomic_store(&mine[65], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // device-scope stores acknowledged before the arrival (see gemv_fx.hip)
+
+  // ---- q, k, v of the new token (waves 0,1,2 take q,k,v) ----
+  if (tid < 192) {
+    const int which = tid >> 6, dd = tid & 63;
+    const int col = which * d + h * 64 + dd;
+    const float* row = p.qkv_part + (size_t)b * 3 * d + col;
+    const size_t sst = (size_t)p.part_rows * 3 * d;
+    float acc = p.qkv_bias ? p.qkv_bias[col] : 0.0f;
+    for (int s = 0; s < p.parts; ++s) acc += row[(size_t)s * sst];
+    if (which == 0) qs[dd] = acc * p.scale;
+    else {
+      const unsigned bits = bf16_rne_bits(acc);
+      unsigned short* dst = which == 1 ? reinterpret_cast<unsigned short*>(kc + (size_t)(dd >> 3) * Smax + pos) + (dd & 7)
+                                       : reinterpret_cast<unsigned short*>(vc + (size_t)pos * 8) + dd;
+      (which == 1 ? knew : vnew)[dd] = __uint_as_float(bits << 16);
+      if (z == 0) *dst = (unsigned short)bits;
+    }
+  }
   __syncthreads();
-  if (tid == 0) {
-    const unsigned old = __hip_atomic_fetch_add(&p.cnt[b * p.H + h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = old == (unsigned)NS - 1u;
-    if (s_last) __hip_atomic_store(&p.cnt[b * p.H + h], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+  const float qlane = qs[lane];
+  float qv[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) qv[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qlane), i));
+
+  auto dot_new = [&]() {
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) dot += qv[i] * knew[i];
+    return dot;
+  };
+  auto dot_key = [&](const u32x4 (&kk)[8]) {
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        dot += qv[8 * i + 2 * j] * __uint_as_float(kk[i][j] << 16) + qv[8 * i + 2 * j + 1] * __uint_as_float(kk[i][j] & 0xffff0000u);
+    return dot;
+  };
+  // ---- scores: one key per thread and pass; the first pass consumes the prefetched key ----
+  float mx = -1e30f;
+  if (s_first <= ke) {
+    const float dot = s_first == pos ? dot_new() : dot_key(kk0);
+    pr[s_first] = dot;
+    mx = dot;
   }
+  for (int s = s_first + NT; s <= ke; s += NT) {
+    float dot;
+    if (s == pos) dot = dot_new();
+    else {
+      u32x4 kk[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) kk[i] = kc[(size_t)i * Smax + s];
+      dot = dot_key(kk);
+    }
+    pr[s] = dot;
+    mx = fmaxf(mx, dot);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
   __syncthreads();
-  if (!s_last || tid >= 64) return;
-  const float* all = p.part + (size_t)(b * p.H + h) * NS * 66;
-  float mi[16], li[16], oi[16];       // every piece's (max, sum, this lane's output) in ONE round trip
+  mx = red[0];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const bool on = i < NS;
-    mi[i] = on ? __hip_atomic_load(&all[i * 66 + 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1e30f;
-    li[i] = on ? __hip_atomic_load(&all[i * 66 + 65], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-    oi[i] = on ? __hip_atomic_load(&all[i * 66 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+  for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w]);
+  float sum = 0.f;
+  for (int s = s_first; s <= ke; s += NT) {
+    const float e = expf(pr[s] - mx);
+    pr[s] = e;
+    sum += e;
   }
-  float M = -1e30f;
+  sum = wave_add(sum);
+  if (lane == 0) red[NW + wave] = sum;
+  __syncthreads();
+  float l = 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) M = fmaxf(M, mi[i]);
-  float O = 0.f, L = 0.f;
+  for (int w = 0; w < NW; ++w) l += red[NW + w];
+
+  // ---- P.V : NG key groups x 8 lanes; a lane owns 8 head dims (one 16-byte load per key), 8 keys in flight per lane ----
+  float a0[8], a1[8];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const float wgt = li[i] > 0.f ? expf(mi[i] - M) : 0.f;
-    O += wgt * oi[i];
-    L += wgt * li[i];
+  for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.f;
+  auto fma8 = [&](float (&acc)[8], const float pw, const u32x4 v) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[2 * j] += pw * __uint_as_float(v[j] << 16);
+      acc[2 * j + 1] += pw * __uint_as_float(v[j] & 0xffff0000u);
+    }
+  };
+  auto fma8_new = [&](float (&acc)[8], const float pw) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += pw * vnew[8 * l8 + e];
+  };
+#pragma unroll
+  for (int j = 0; j < VP; ++j) {
+    const int sj = ks + grp + NG * j;
+    if (sj <= ke) {
+      if (sj == pos) fma8_new((j & 1) ? a1 : a0, pr[sj]);
+      else fma8((j & 1) ? a1 : a0, pr[sj], vpre[j]);
+    }
   }
-  p.out[frag_index(b, h * 64 + tid, d >> 4)] = L > 0.f ? O / L : 0.f;
+  for (int sb = ks + grp + VP * NG; sb <= ke; sb += 8 * NG) {
+    u32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int sj = sb + NG * j;
+      v[j] = (sj < pos && sj <= ke) ? vc[(size_t)sj * 8 + l8] : zero4;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int sj = sb + NG * j;
+      if (sj <= ke) {
+        if (sj == pos) fma8_new((j & 1) ? a1 : a0, pr[sj]);
+        else fma8((j & 1) ? a1 : a0, pr[sj], v[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) outp[grp * 64 + 8 * l8 + e] = a0[e] + a1[e];
+  __syncthreads();
+  float o = 0.f;
+  if (tid < 64) {
+#pragma unroll 16
+    for (int g = 0; g < NG; ++g) o += outp[g * 64 + tid];
+  }
+  decode_attn_finish(p, b, h, z, NS, tid, o, mx, l);
 }
 
 int decode_attn_nsplit(int B, int H) {
   const int wgs = B * H;
+  // (bf16 cache, 320 workgroups: two / three key pieces per (utterance, head) measured 185 / 215 ms per step against 156 unsplit)
   return wgs <= 128 ? std::max(1, std::min(16, 256 / wgs)) : 1;
 }
 
@@ -227,18 +414,20 @@ int decode_attn_forward(const DecodeAttnArgs& a, hipStream_t stream) {
   IDX_CHECK(a.qkv_part && a.kcache && a.vcache && a.out && a.st, "null pointer");
   IDX_CHECK(a.d == a.H * 64, "head_dim must be 64");
   constexpr int nt = 512;      // 512 threads measured 4 % faster than 256 (profiles/README.md)
-  const size_t lds = (size_t)(256 + (nt / 16) * 64 + a.Smax) * sizeof(float);
+  const size_t lds = (size_t)(256 + (nt / (a.kv16 ? 8 : 16)) * 64 + a.Smax) * sizeof(float);
   IDX_CHECK(lds <= 128 * 1024, "Smax too large for the LDS score buffer");
   static bool attr_set = false;
   if (!attr_set) {
     IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_attn_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_attn16_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     attr_set = true;
   }
   IDX_CHECK(a.nsplit >= 1 && a.nsplit <= 16 && (a.nsplit == 1 || (a.part && a.cnt)), "key split: 1..16 pieces, partial buffer and counters");
-  // algorithmic bytes: K and V of every cached position, all heads: B * S * 2 * d * 4 (S as the host knows it: pos_hint)
-  static const int cat = prof_register("decode_attn_kernel");
-  ProfScope prof(cat, stream, 0.0, 8.0 * a.B * (double)a.pos_hint * a.d);
-  hipLaunchKernelGGL(decode_attn_kernel<512>, dim3(a.H, a.B, a.nsplit), dim3(512), lds, stream, a);
+  // algorithmic bytes: K and V of every cached position, all heads: B * S * 2 * d * (4 | 2) (S as the host knows it: pos_hint)
+  static const int cat = prof_register("decode_attn_kernel"), cat16 = prof_register("decode_attn16_kernel");
+  ProfScope prof(a.kv16 ? cat16 : cat, stream, 0.0, (a.kv16 ? 4.0 : 8.0) * a.B * (double)a.pos_hint * a.d);
+  if (a.kv16) hipLaunchKernelGGL(decode_attn16_kernel<512>, dim3(a.H, a.B, a.nsplit), dim3(512), lds, stream, a);
+  else hipLaunchKernelGGL(decode_attn_kernel<512>, dim3(a.H, a.B, a.nsplit), dim3(512), lds, stream, a);
   IDX_LAUNCH_CHECK();
   return 0;
 }
@@ -493,22 +682,31 @@ int advance_state(DecodeState* st, hipStream_t stream) {
 }
 
 // qkv [B][S][3d] (token-major, after bias) -> K/V caches, positions [0, S)
-__global__ __launch_bounds__(256) void kv_store_prefill_kernel(const float* qkv, float* kcache, float* vcache, int B, int H,
-                                                               int S, int Smax, int d) {
+template <bool KV16>
+__global__ __launch_bounds__(256) void kv_store_prefill_kernel(float* qkv, void* kcache, void* vcache, int B, int H, int S, int Smax, int d) {
   const int s = blockIdx.x, b = blockIdx.y;
-  const float* row = qkv + ((size_t)b * S + s) * 3 * d;
+  float* row = qkv + ((size_t)b * S + s) * 3 * d;
   for (int col = threadIdx.x; col < d; col += 256) {
     const int h = col >> 6, dd = col & 63;
-    kcache[(((size_t)(b * H + h) * 16 + (dd >> 2)) * Smax + s) * 4 + (dd & 3)] = row[d + col];
-    vcache[((size_t)(b * H + h) * Smax + s) * 64 + dd] = row[2 * d + col];
+    if (KV16) {      // bf16 cache; the fp32 row keeps the rounded values for the prefill attention
+      const unsigned kb = bf16_rne_bits(row[d + col]), vb = bf16_rne_bits(row[2 * d + col]);
+      static_cast<unsigned short*>(kcache)[(((size_t)(b * H + h) * 8 + (dd >> 3)) * Smax + s) * 8 + (dd & 7)] = (unsigned short)kb;
+      static_cast<unsigned short*>(vcache)[((size_t)(b * H + h) * Smax + s) * 64 + dd] = (unsigned short)vb;
+      row[d + col] = __uint_as_float(kb << 16);
+      row[2 * d + col] = __uint_as_float(vb << 16);
+    } else {
+      static_cast<float*>(kcache)[(((size_t)(b * H + h) * 16 + (dd >> 2)) * Smax + s) * 4 + (dd & 3)] = row[d + col];
+      static_cast<float*>(vcache)[((size_t)(b * H + h) * Smax + s) * 64 + dd] = row[2 * d + col];
+    }
   }
 }
 
-int kv_store_prefill(const float* qkv, float* kcache, float* vcache, int B, int H, int S, int Smax, int d, hipStream_t stream) {
+int kv_store_prefill(float* qkv, void* kcache, void* vcache, int kv16, int B, int H, int S, int Smax, int d, hipStream_t stream) {
   IDX_CHECK(S <= Smax, "prefill longer than the cache");
   static const int cat = prof_register("kv_store_prefill_kernel");
-  ProfScope prof(cat, stream, 0.0, 16.0 * B * (double)S * d);
-  hipLaunchKernelGGL(kv_store_prefill_kernel, dim3(S, B), dim3(256), 0, stream, qkv, kcache, vcache, B, H, S, Smax, d);
+  ProfScope prof(cat, stream, 0.0, (kv16 ? 28.0 : 16.0) * B * (double)S * d);
+  if (kv16) hipLaunchKernelGGL(kv_store_prefill_kernel<true>, dim3(S, B), dim3(256), 0, stream, qkv, kcache, vcache, B, H, S, Smax, d);
+  else hipLaunchKernelGGL(kv_store_prefill_kernel<false>, dim3(S, B), dim3(256), 0, stream, qkv, kcache, vcache, B, H, S, Smax, d);
   IDX_LAUNCH_CHECK();
   return 0;
 }

@@ -31,6 +31,8 @@ struct GPTModel : ModelBase {
   const float* head_b = nullptr;
   const float *mel_emb = nullptr, *text_emb = nullptr, *mel_pos = nullptr, *text_pos = nullptr;
   int weight_fmt = WFMT_F32;      // storage format of the decode weight streams (quantize_weights)
+  int kv_fmt = 0;                 // KV cache of the cached generation: 0 = fp32, 1 = bf16 (keys / values rounded when produced; decode.h)
+  size_t kv_layer_bytes(int B, int Smax) const { return (size_t)B * cfg.heads * Smax * 64 * (kv_fmt ? 2 : 4); }
   hipStream_t own_stream = nullptr;
   static constexpr int OOB_SLOTS = 64;
   int* oob_flag = nullptr;        // device ints (one per embed() call in flight): set by the embedding gather when an index exceeds its table
@@ -42,7 +44,7 @@ struct GPTModel : ModelBase {
 
   struct Buffers {
     float *x, *h, *qkv, *att, *ff;            // [B*S][..] prefill / latent activations
-    float *kcache, *vcache; int Smax;         // [L][B][H][Smax][64] each
+    char *kcache, *vcache; int Smax;          // [L][B][H] x (Smax x 64 elements) each; fp32 or bf16 elements (kv_fmt, decode.h)
     float *xd, *hd, *attd, *ffd;              // decode residual / final-normed / attention output / mlp hidden: A-fragment images
     float *qkvd, *logits, *slab;              // [B][3d], [B][V] row-major; [<=8][B][d] K-split partial sums of mlp.c_proj
     size_t frag_off, frag_bytes;              // the fragment-image region (zeroed once per generate: padding rows stay 0)
@@ -56,7 +58,7 @@ struct GPTModel : ModelBase {
   // Instantiated decode-step graphs of greedy generations, keyed by everything the captured launches depend on (workspace
   // address and carve, batch, penalty): a server replaying the same shapes on the same stream re-captures nothing.
   struct GraphSlot {
-    void* ws = nullptr; size_t ws_bytes = 0; int B = 0, S = 0, max_new = 0; float penalty = 0.0f;
+    void* ws = nullptr; size_t ws_bytes = 0; int B = 0, S = 0, max_new = 0; float penalty = 0.0f; int kv16 = 0;
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; unsigned long stamp = 0; bool in_use = false;
   };
   std::vector<GraphSlot> graph_cache;

@@ -230,9 +230,9 @@ GPTModel::Buffers GPTModel::carve(void* ws, int B, int S, int max_new) const {
   b.att = c.take<float>(rows * d);
   b.ff = c.take<float>(rows * 4 * d);
   b.Smax = max_new > 0 ? ((S + max_new + 3) & ~3) : 0;
-  const size_t cache = (size_t)L * B * cfg.heads * b.Smax * 64;
-  b.kcache = c.take<float>(cache);
-  b.vcache = c.take<float>(cache);
+  const size_t cache = (size_t)L * kv_layer_bytes(B, b.Smax);
+  b.kcache = c.take<char>(cache);
+  b.vcache = c.take<char>(cache);
   // decode activations as A-fragment images (frag_index, common.h); one contiguous region so it can be zeroed in one go
   b.xd = c.take<float>(frag_image_floats(B, d));
   b.frag_off = c.off - frag_image_floats(B, d) * sizeof(float);
@@ -271,8 +271,8 @@ int GPTModel::layer_full(int li, const Buffers& w, int B, int S, const int* ksta
   g.x = w.h; g.ldx = d; g.y = w.qkv; g.ldy = 3 * d; g.M = M;
   if (mm(L.attn_l, g)) return 1;
   if (store_kv) {
-    const size_t per_layer = (size_t)B * cfg.heads * w.Smax * 64;
-    if (kv_store_prefill(w.qkv, w.kcache + li * per_layer, w.vcache + li * per_layer, B, cfg.heads, S, w.Smax, d, st)) return 1;
+    const size_t per_layer = kv_layer_bytes(B, w.Smax);
+    if (kv_store_prefill(w.qkv, w.kcache + li * per_layer, w.vcache + li * per_layer, kv_fmt, B, cfg.heads, S, w.Smax, d, st)) return 1;
   }
   AttnArgs a;
   a.q = w.qkv; a.k = w.qkv + d; a.v = w.qkv + 2 * d; a.o = w.att;
@@ -332,7 +332,7 @@ int GPTModel::head_and_sample(const Buffers& w, int B, const float* x, int ldx, 
 int GPTModel::decode_step(const Buffers& w, int B, float penalty, long long* codes, int codes_ld, float* logits_base,
                           hipStream_t st) {
   const int d = cfg.model_dim;
-  const size_t per_layer = (size_t)B * cfg.heads * w.Smax * 64;
+  const size_t per_layer = kv_layer_bytes(B, w.Smax);
   if (embed_step(w.xd, B, d, mel_emb, mel_pos, w.cur_tok, w.state, st)) return 1;
   for (int li = 0; li < cfg.layers; ++li) {
     const GPTLayer& L = layers[li];
@@ -341,7 +341,7 @@ int GPTModel::decode_step(const Buffers& w, int B, float penalty, long long* cod
     if (gemv_fx_forward(L.attn_g, qa, st)) return 1;
     DecodeAttnArgs da;
     da.qkv_part = w.qkvd; da.parts = 1; da.part_rows = B; da.qkv_bias = nullptr;
-    da.kcache = w.kcache + li * per_layer; da.vcache = w.vcache + li * per_layer; da.out = w.attd; da.kstart = w.kstart;
+    da.kcache = w.kcache + li * per_layer; da.vcache = w.vcache + li * per_layer; da.kv16 = kv_fmt; da.out = w.attd; da.kstart = w.kstart;
     da.st = w.state; da.B = B; da.H = cfg.heads; da.Smax = w.Smax; da.d = d; da.scale = 0.125f;
     da.nsplit = decode_attn_nsplit(B, cfg.heads); da.part = w.attn_part; da.cnt = w.attn_cnt;
     da.pos_hint = tl_prof_pos;
@@ -459,7 +459,7 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
       std::lock_guard<std::mutex> l(graph_mu);
       for (size_t i = 0; i < graph_cache.size(); ++i) {
         GraphSlot& g = graph_cache[i];
-        if (!g.in_use && g.ws == ws && g.ws_bytes == ws_bytes && g.B == B && g.S == S && g.max_new == max_new && g.penalty == penalty) {
+        if (!g.in_use && g.ws == ws && g.ws_bytes == ws_bytes && g.B == B && g.S == S && g.max_new == max_new && g.penalty == penalty && g.kv16 == kv_fmt) {
           g.in_use = true; g.stamp = ++graph_stamp; exec = g.exec; lease.m = this; lease.idx = (int)i;
           break;
         }
@@ -487,7 +487,7 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
           GraphSlot& g = graph_cache[slot];
           if (g.exec) (void)hipGraphExecDestroy(g.exec);
           if (g.graph) (void)hipGraphDestroy(g.graph);
-          g.ws = ws; g.ws_bytes = ws_bytes; g.B = B; g.S = S; g.max_new = max_new; g.penalty = penalty;
+          g.ws = ws; g.ws_bytes = ws_bytes; g.B = B; g.S = S; g.max_new = max_new; g.penalty = penalty; g.kv16 = kv_fmt;
           g.graph = gg.graph; g.exec = gg.exec; g.stamp = ++graph_stamp; g.in_use = true;
           gg.graph = nullptr; gg.exec = nullptr;
           lease.m = this; lease.idx = slot;

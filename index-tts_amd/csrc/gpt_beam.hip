@@ -117,7 +117,7 @@ int GPTModel::generate_beam(const float* inputs_embeds, const int* pad_left_host
   bst.beam_idx = bb.beam_idx; bst.seq = bb.seq; bst.seq_ld = max_new; bst.cur_tok = w.cur_tok;
   bst.hyp_score = bb.hyp_score; bst.hyp_len = bb.hyp_len; bst.hyp_slot = bb.hyp_slot; bst.hyp_seq = bb.hyp_seq; bst.hyp_n = bb.hyp_n;
   bst.hyp_worst = bb.hyp_worst; bst.done = bb.done; bst.st = w.state; bst.exp_noise = beam->exp_noise; bst.seed = beam->seed;
-  bst.kcache = w.kcache; bst.vcache = w.vcache;
+  bst.kcache = w.kcache; bst.vcache = w.vcache; bst.kv_gran = kv_fmt ? 8 : 16;
   bst.B = B; bst.nb = nb; bst.V = V; bst.stop_token = cfg.stop_mel_token; bst.L = cfg.layers; bst.H = cfg.heads; bst.Smax = w.Smax;
   bst.prompt_len = S;
   bst.do_sample = beam->do_sample ? 1 : 0; bst.top_k = beam->top_k; bst.early_stopping = beam->early_stopping;

@@ -31,20 +31,30 @@ def _i32(dev, arr) -> torch.Tensor:
 
 
 WEIGHT_FORMATS = {"f32": 0, "bf16": 1, "fp8": 2}
+KV_FORMATS = {"f32": 0, "bf16": 1}
 
 
 class UnifiedVoice:
     MAX_WORKSPACES = 4
 
-    def __init__(self, state_dict, cfg: GPTConfig = GPTConfig(), device="cuda:0", weight_format: str = "f32", keep_effective: bool = False):
+    def __init__(self, state_dict, cfg: GPTConfig = GPTConfig(), device="cuda:0", weight_format: str = "f32", keep_effective: bool = False,
+                 kv_format: str = None):
         """weight_format: storage of the GPT's linear weights -- "f32" (default), "bf16", or "fp8" (e4m3 + power-of-two scale
         per output channel): the reference's `use_fp16` switch (infer_v2.py:145-146) / BASELINE configs[4].  The weights are
         rounded ONCE at load (`idxtts_gpt_quantize_weights`); the arithmetic stays fp32, and every pass runs that one rounded
-        model.  keep_effective: keep `self.effective_state_dict` (numpy, reference keys) = exactly that model, for parity checks."""
+        model.  keep_effective: keep `self.effective_state_dict` (numpy, reference keys) = exactly that model, for parity checks.
+        kv_format: storage of the KV cache of the cached generation, "f32" or "bf16" (`idxtts_gpt_set_kv_format`: keys / values
+        rounded to bf16 once, when produced; fp32 arithmetic).  Default: "f32" with fp32 weights, "bf16" with compact weights --
+        the reference's `use_fp16` halves weights and cache together."""
         lib = _lib.load()
         if weight_format not in WEIGHT_FORMATS:
             raise ValueError(f"weight_format must be one of {sorted(WEIGHT_FORMATS)}")
         self.weight_format = weight_format
+        if kv_format is None:
+            kv_format = "f32" if weight_format == "f32" else "bf16"
+        if kv_format not in KV_FORMATS:
+            raise ValueError(f"kv_format must be one of {sorted(KV_FORMATS)}")
+        self.kv_format = kv_format
         self.effective_state_dict = None
         self.cfg = cfg
         self.device = torch.device(device)
@@ -64,6 +74,7 @@ class UnifiedVoice:
                 if keep_effective:
                     self.effective_state_dict = {k: _lib.get_tensor(ctx, k, tuple(v.shape)) for k, v in sd.items()}
             _lib.load_state_dict(h, sd, before_finalize=hook)
+            _lib.check(lib.idxtts_gpt_set_kv_format(h, KV_FORMATS[kv_format]))
         from .cond import ConditioningEncoders
         self.cond = ConditioningEncoders(state_dict, cfg, device=self.device) if ConditioningEncoders.has_weights(state_dict) else None
         se = state_dict["speed_emb.weight"]
@@ -74,6 +85,13 @@ class UnifiedVoice:
         self.stop_mel_token = cfg.stop_mel_token
         self.start_mel_token = cfg.start_mel_token
         self.accel_engine = self       # the reference selects `self.accel_engine.generate` (model_v2.py:871)
+
+    def set_kv_format(self, kv_format: str) -> None:
+        """Switch the KV-cache storage between generations ("f32" | "bf16")."""
+        if kv_format not in KV_FORMATS:
+            raise ValueError(f"kv_format must be one of {sorted(KV_FORMATS)}")
+        _lib.check(_lib.load().idxtts_gpt_set_kv_format(self._h, KV_FORMATS[kv_format]))
+        self.kv_format = kv_format
 
     @staticmethod
     def _on_path(key: str) -> bool:

@@ -125,7 +125,7 @@ class IndexTTS2:
 
     def __init__(self, cfg_path="checkpoints/config.yaml", model_dir="checkpoints", use_fp16=False, device=None,
                  use_cuda_kernel=None, use_deepspeed=False, use_accel=False, use_torch_compile=False, gpt_weight_format=None,
-                 segment_batch: int = 16):
+                 segment_batch: int = 16, gpt_kv_format=None):
         # use_fp16 (reference: gpt.half() + fp16 autocast, infer_v2.py:109, 145-146) maps to bf16 STORAGE of the GPT weights:
         # the arithmetic of the HIP path stays fp32.  gpt_weight_format ("f32" | "bf16" | "fp8") overrides it.
         if gpt_weight_format is None:
@@ -137,7 +137,7 @@ class IndexTTS2:
         from .checkpoint import config_from_yaml, load_reference_checkpoints
         cfg, raw = config_from_yaml(cfg_path, model_dir) if os.path.exists(cfg_path) else (PipelineConfig(), None)
         gpt_sd, s2mel_sd, voc_sd = load_reference_checkpoints(model_dir, raw)
-        self._init(cfg, gpt_sd, s2mel_sd, voc_sd, device, gpt_weight_format, segment_batch=segment_batch)
+        self._init(cfg, gpt_sd, s2mel_sd, voc_sd, device, gpt_weight_format, segment_batch=segment_batch, gpt_kv_format=gpt_kv_format)
         # the rest of the reference's constructor (infer_v2.py:187-289): semantic model + statistics, semantic codec, CAMPPlus,
         # emotion banks, tokenizer
         from .checkpoint import load_prompt_checkpoints, reference_text_normalizer
@@ -159,22 +159,25 @@ class IndexTTS2:
 
     @classmethod
     def from_state_dicts(cls, cfg: PipelineConfig, gpt_sd, s2mel_sd, bigvgan_sd, device=None, gpt_weight_format="f32",
-                         keep_effective_gpt=False, segment_batch: int = 16) -> "IndexTTS2":
-        """gpt_weight_format: "f32" | "bf16" | "fp8" storage of the GPT linear weights (UnifiedVoice); keep_effective_gpt keeps
+                         keep_effective_gpt=False, segment_batch: int = 16, gpt_kv_format=None) -> "IndexTTS2":
+        """gpt_weight_format: "f32" | "bf16" | "fp8" storage of the GPT linear weights, gpt_kv_format: "f32" | "bf16" storage of its KV
+        cache (default: fp32 with fp32 weights, bf16 with compact weights) (UnifiedVoice); keep_effective_gpt keeps
         `self.gpt.effective_state_dict` (the rounded model, reference keys) for parity checks; segment_batch: segments of one
         infer() call synthesised together (1 = the reference's loop as written)."""
         self = cls.__new__(cls)
-        self._init(cfg, gpt_sd, s2mel_sd, bigvgan_sd, device, gpt_weight_format, keep_effective_gpt, segment_batch)
+        self._init(cfg, gpt_sd, s2mel_sd, bigvgan_sd, device, gpt_weight_format, keep_effective_gpt, segment_batch, gpt_kv_format)
         return self
 
-    def _init(self, cfg, gpt_sd, s2mel_sd, bigvgan_sd, device, gpt_weight_format="f32", keep_effective_gpt=False, segment_batch=16):
+    def _init(self, cfg, gpt_sd, s2mel_sd, bigvgan_sd, device, gpt_weight_format="f32", keep_effective_gpt=False, segment_batch=16,
+              gpt_kv_format=None):
         if device is None:
             device = f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cpu"
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("IndexTTS2 (HIP path) needs an MI355X device; there is no CPU fallback")
         self.cfg = cfg
-        self.gpt = UnifiedVoice(gpt_sd, cfg.gpt, device=self.device, weight_format=gpt_weight_format, keep_effective=keep_effective_gpt)
+        self.gpt = UnifiedVoice(gpt_sd, cfg.gpt, device=self.device, weight_format=gpt_weight_format, keep_effective=keep_effective_gpt,
+                                kv_format=gpt_kv_format)
         self.s2mel = S2Mel(s2mel_sd, cfg.s2mel, device=self.device)
         self.bigvgan = BigVGAN(bigvgan_sd, cfg.bigvgan)
         self.stop_mel_token = cfg.gpt.stop_mel_token

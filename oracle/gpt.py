@@ -39,11 +39,14 @@ def gelu_new(x: torch.Tensor) -> torch.Tensor:
 
 
 def gpt2_stack(w, cfg, emb: torch.Tensor, key_valid: Optional[torch.Tensor] = None,
-               past: Optional[list] = None) -> Tuple[torch.Tensor, list]:
+               past: Optional[list] = None, kv_round: bool = False) -> Tuple[torch.Tensor, list]:
     """emb [B,S,d] (already includes the learned positions; HF wpe is nulled) -> ln_f(hidden) [B,S,d].
 
     key_valid: [B, past_len+S] bool/0-1 (the HF `attention_mask`), None = all valid.
-    past: per-layer (K,V) each [B,H,past_len,hd].  Returns (hidden, present)."""
+    past: per-layer (K,V) each [B,H,past_len,hd].  Returns (hidden, present).
+    kv_round: the bf16 KV-cache mode of the HIP path (include/idxtts.h::idxtts_gpt_set_kv_format; the reference's `use_fp16`
+    keeps `past_key_values` in half precision, infer_v2.py:145-146): every key / value is rounded to bf16 (nearest even) when it
+    is produced, prefill and decode alike, and used at that value from then on; all arithmetic stays fp32."""
     B, S, d = emb.shape
     H, hd = cfg.heads, cfg.head_dim
     past_len = 0 if past is None else past[0][0].shape[2]
@@ -63,6 +66,8 @@ def gpt2_stack(w, cfg, emb: torch.Tensor, key_valid: Optional[torch.Tensor] = No
         q = q.view(B, S, H, hd).transpose(1, 2)
         k = k.view(B, S, H, hd).transpose(1, 2)
         v = v.view(B, S, H, hd).transpose(1, 2)
+        if kv_round:
+            k, v = k.to(torch.bfloat16).to(torch.float32), v.to(torch.bfloat16).to(torch.float32)
         if past is not None:
             k = torch.cat([past[i][0], k], dim=2)
             v = torch.cat([past[i][1], v], dim=2)
@@ -131,7 +136,7 @@ def repetition_penalty(input_ids: torch.Tensor, scores: torch.Tensor, penalty: f
 
 
 def generate_greedy(w, cfg, conds: torch.Tensor, text_inputs: torch.Tensor, max_new_tokens: int,
-                    repetition_penalty_value: float = 10.0, return_logits: bool = False):
+                    repetition_penalty_value: float = 10.0, return_logits: bool = False, kv_round: bool = False):
     """inference_speech (model_v2.py:835-892) with do_sample=False, num_beams=1.
     Returns codes [B, n_steps] (eos and post-eos pad = stop_mel_token included, as HF returns them)."""
     fake, inputs_embeds, attention_mask = prepare_gpt_inputs(w, cfg, conds, text_inputs)
@@ -148,7 +153,7 @@ def generate_greedy(w, cfg, conds: torch.Tensor, text_inputs: torch.Tensor, max_
         else:                # decode: position = attention_mask.shape[1] - mel_len  (model_v2.py:175-177)
             pos = attention_mask.shape[1] - P
             emb = (me[input_ids[:, -1]] + mp[pos])[:, None, :]
-        hidden, past = gpt2_stack(w, cfg, emb, attention_mask, past)
+        hidden, past = gpt2_stack(w, cfg, emb, attention_mask, past, kv_round)
         logits = lm_head(w, cfg, hidden[:, -1]).float()
         if return_logits:
             all_logits.append(logits.clone())
@@ -188,7 +193,7 @@ def warp_scores(scores: torch.Tensor, temperature: float, top_k: int, top_p: flo
 
 def generate_sample(w, cfg, conds: torch.Tensor, text_inputs: torch.Tensor, max_new_tokens: int, exp_noise: torch.Tensor,
                     repetition_penalty_value: float = 10.0, temperature: float = 0.8, top_k: int = 30, top_p: float = 0.8,
-                    accel_sampler: bool = False):
+                    accel_sampler: bool = False, kv_round: bool = False):
     """inference_speech (model_v2.py:835-892) with do_sample=True, num_beams=1: HF _sample
     (transformers_generation_utils.py:3196-3262): repetition penalty -> warpers -> softmax -> torch.multinomial(probs, 1).
     torch.multinomial with one sample per row IS argmax(probs / q), q ~ Exp(1) drawn by ONE exponential_() call on a
@@ -208,7 +213,7 @@ def generate_sample(w, cfg, conds: torch.Tensor, text_inputs: torch.Tensor, max_
         else:
             pos = attention_mask.shape[1] - P
             emb = (me[input_ids[:, -1]] + mp[pos])[:, None, :]
-        hidden, past = gpt2_stack(w, cfg, emb, attention_mask, past)
+        hidden, past = gpt2_stack(w, cfg, emb, attention_mask, past, kv_round)
         logits = lm_head(w, cfg, hidden[:, -1]).float()
         q = exp_noise[step].float()
         if accel_sampler:
@@ -258,7 +263,7 @@ class _BeamHyps:
 def generate_beam(w, cfg, conds: torch.Tensor, text_inputs: torch.Tensor, max_new_tokens: int, exp_noise: Optional[torch.Tensor],
                   num_beams: int = 3, repetition_penalty_value: float = 10.0, temperature: float = 0.8, top_k: int = 30,
                   top_p: float = 0.8, length_penalty: float = 0.0, do_sample: bool = True, early_stopping: bool = False,
-                  return_trace: bool = False):
+                  return_trace: bool = False, kv_round: bool = False):
     """inference_speech (model_v2.py:835-892) with num_beams > 1 -- the mode `IndexTTS2.infer` really runs by default
     (infer_v2.py:714-722, 767: do_sample=True, num_beams=3, top_p=.8, top_k=30, temperature=.8, repetition_penalty=10,
     length_penalty=0).  Restates the vendored `GenerationMixin._beam_search` (transformers_generation_utils.py:3325-3516):
@@ -294,7 +299,7 @@ def generate_beam(w, cfg, conds: torch.Tensor, text_inputs: torch.Tensor, max_ne
             emb = torch.cat([embeds, start], dim=1)
         else:
             emb = (me[input_ids[:, -1]] + mp[attention_mask.shape[1] - P])[:, None, :]
-        hidden, past = gpt2_stack(w, cfg, emb, attention_mask, past)
+        hidden, past = gpt2_stack(w, cfg, emb, attention_mask, past, kv_round)
         logits = lm_head(w, cfg, hidden[:, -1]).float()
         scores = F.log_softmax(logits, dim=-1)
         proc = repetition_penalty(input_ids, scores, repetition_penalty_value) if repetition_penalty_value != 1.0 else scores

@@ -14,14 +14,14 @@ from . import vocoder as ov
 
 
 def synthesize_one(w_gpt, w_s2mel, w_voc, cfg, text_tokens: torch.Tensor, cond, noise: torch.Tensor, max_mel_tokens: int,
-                   repetition_penalty: float = 10.0, diffusion_steps: int = None, cfg_rate: float = None):
+                   repetition_penalty: float = 10.0, diffusion_steps: int = None, cfg_rate: float = None, kv_round: bool = False):
     """text_tokens [1, L] (no padding), cond = object with the PromptConditioning fields (CPU tensors),
-    noise [1, 80, >= Tp + Tg].  Returns dict(codes, latent, cond, mel, wav)."""
+    noise [1, 80, >= Tp + Tg].  kv_round: the bf16 KV-cache mode (oracle/gpt.py::gpt2_stack).  Returns dict(codes, latent, cond, mel, wav)."""
     g = cfg.gpt
     steps = cfg.diffusion_steps if diffusion_steps is None else diffusion_steps
     rate = cfg.cfg_rate if cfg_rate is None else cfg_rate
     conds = og.conds_latent(w_gpt, g, cond.spk_cond_latent, cond.emo_vec)
-    codes = og.generate_greedy(w_gpt, g, conds, text_tokens, max_mel_tokens, repetition_penalty)            # infer_v2.py:760-777
+    codes = og.generate_greedy(w_gpt, g, conds, text_tokens, max_mel_tokens, repetition_penalty, kv_round=kv_round)   # infer_v2.py:760-777
     row = codes[0].numpy()
     hits = np.nonzero(row == g.stop_mel_token)[0]
     code_len = int(hits[0]) if len(hits) else len(row)                                                      # 795-807

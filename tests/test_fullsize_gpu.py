@@ -52,8 +52,8 @@ def test_config4_longform_decode_graph_equals_eager_and_oracle(device, full):
     assert np.array_equal(runs[True], runs[False])
     assert len(np.unique(runs[True])) > 50                      # not a degenerate loop
     tw = {k: torch.from_numpy(v) for k, v in uv.effective_state_dict.items()}
-    ref = og.generate_greedy(tw, cfg.gpt, og.conds_latent(tw, cfg.gpt, c.spk_cond_latent, emo), text, 24, 10.0)
-    assert np.array_equal(runs[True][:, :24], ref.numpy())
+    ref = og.generate_greedy(tw, cfg.gpt, og.conds_latent(tw, cfg.gpt, c.spk_cond_latent, emo), text, 24, 10.0, kv_round=uv.kv_format == "bf16")
+    assert uv.kv_format == "bf16" and np.array_equal(runs[True][:, :24], ref.numpy())
 
 
 def test_config4_estimator_at_full_length_vs_oracle(device, full):
@@ -221,3 +221,28 @@ def test_beam_search_at_full_size_16_utterances_vs_oracle(device, full):
         # exact-fp32 kernels vs torch CPU: summation order differs, so a near-tie between candidates may flip a row once in a while;
         # at most one of the 16 utterances may differ, and every row must agree up to its first differing token's neighbourhood
         assert mism <= 1, f"{mism} of {B} utterances differ (do_sample={do_sample})"
+
+
+def test_bf16_weights_and_kv_cache_16_utterances_vs_oracle(device, full):
+    """configs[2]'s decode as bench.py runs it: the full-size GPT, 16 utterances (20 heads x 16 = 320 attention workgroups, no key
+    split), bf16 weight streams AND the bf16 KV cache -- the first 16 greedy codes of every utterance against the CPU oracle on
+    the read-back rounded model with the same key / value rounding (kv_round), ragged text lengths (left padding)."""
+    from indextts_amd.gpt import UnifiedVoice
+    from oracle import gpt as og
+    cfg, wg, ws, wv = full
+    g = cfg.gpt
+    uv = UnifiedVoice(wg, g, device=device, weight_format="bf16", keep_effective=True)
+    assert uv.kv_format == "bf16"
+    tw = {k: torch.from_numpy(v) for k, v in uv.effective_state_dict.items()}
+    c = _cond(cfg)
+    B, L, NEW = 16, 40, 16
+    text = torch.from_numpy(synth.integers("t/full/kv16/text", (B, L), 2, g.number_text_tokens))
+    for b in range(B):
+        text[b, L - (b % 5) * 3:] = g.stop_text_token
+    lat, emo = c.spk_cond_latent.expand(B, -1, -1), c.emo_vec.expand(B, -1)
+    codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, do_sample=False, num_beams=1, repetition_penalty=10.0)
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        ref = og.generate_greedy(tw, g, og.conds_latent(tw, g, lat, emo), text, NEW, 10.0, kv_round=True)
+    got = codes.cpu().numpy()
+    assert got.shape == tuple(ref.shape) and np.array_equal(got, ref.numpy())

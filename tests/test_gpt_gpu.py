@@ -450,13 +450,15 @@ def _check_effective(orig, eff, cfg, fmt):
 def test_compact_weights_generate_and_latent_vs_oracle_on_the_same_model(device, fmt):
     """Weights stored as bf16 / fp8-e4m3 (+ power-of-two column scale): the rounded model is read back through the C ABI and
     handed to the fp32 CPU oracle -- greedy codes bit-exact, latent within the fp32 tolerance; and the read-back model is
-    checked to be exactly the documented rounding of the original one."""
+    checked to be exactly the documented rounding of the original one.  Compact weights bring the bf16 KV cache with them
+    (the reference's `use_fp16` halves both): the oracle rounds keys / values the same way (kv_round)."""
     from indextts_amd.gpt import UnifiedVoice
     from oracle import gpt as og
     cfg = GPTConfig(model_dim=128, heads=2, layers=3, number_mel_codes=210, number_text_tokens=60, start_mel_token=208, stop_mel_token=209,
                     max_mel_tokens=60, max_text_tokens=30)
     w = weights.synth_gpt_weights(cfg, tag=f"t/gpt/q/{fmt}")
     uv = UnifiedVoice(w, cfg, device=device, weight_format=fmt, keep_effective=True)
+    assert uv.kv_format == "bf16"
     eff = uv.effective_state_dict
     _check_effective(w, eff, cfg, fmt)
     tw = {k: torch.from_numpy(v) for k, v in eff.items()}
@@ -466,8 +468,14 @@ def test_compact_weights_generate_and_latent_vs_oracle_on_the_same_model(device,
     text = torch.from_numpy(synth.integers("t/gpt/q/text", (B, L), 2, cfg.number_text_tokens))
     codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, repetition_penalty=10.0)
     with torch.no_grad():
-        ref = og.generate_greedy(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, NEW, 10.0)
+        ref = og.generate_greedy(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, NEW, 10.0, kv_round=True)
     assert np.array_equal(codes.cpu().numpy(), ref.numpy())
+    uv.set_kv_format("f32")                                 # compact weights with the fp32 cache: the oracle without the rounding
+    codes32, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, repetition_penalty=10.0)
+    with torch.no_grad():
+        ref32 = og.generate_greedy(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, NEW, 10.0)
+    assert np.array_equal(codes32.cpu().numpy(), ref32.numpy())
+    uv.set_kv_format("bf16")
     n = ref.shape[1]
     got = uv.forward(lat, text, torch.full((B,), L), codes.cpu(), torch.full((B,), n), emo_vec=emo).cpu()
     with torch.no_grad():
@@ -490,8 +498,8 @@ def test_fp8_full_size_single_utterance_vs_oracle(device):
     text = torch.from_numpy(synth.integers("t/gpt/q8/text", (1, L), 2, cfg.number_text_tokens))
     codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, repetition_penalty=10.0)
     with torch.no_grad():
-        ref = og.generate_greedy(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, NEW, 10.0)
-    assert np.array_equal(codes.cpu().numpy(), ref.numpy())
+        ref = og.generate_greedy(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, NEW, 10.0, kv_round=uv.kv_format == "bf16")
+    assert uv.kv_format == "bf16" and np.array_equal(codes.cpu().numpy(), ref.numpy())
 
 
 def test_maximum_text_length_and_long_decode_vs_oracle(device):
@@ -515,3 +523,63 @@ def test_maximum_text_length_and_long_decode_vs_oracle(device):
     with torch.no_grad():
         ref = og.generate_greedy(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, NEW, 10.0)
     assert codes.shape[1] == NEW and np.array_equal(codes.cpu().numpy(), ref.numpy())
+
+
+@pytest.mark.parametrize("B,heads", [(2, 2), (9, 16)])
+def test_bf16_kv_cache_long_decode_vs_oracle(device, B, heads):
+    """idxtts_gpt_set_kv_format(1) on fp32 weights: keys / values rounded to bf16 when produced (prefill and decode), fp32 arithmetic --
+    greedy codes bit-exact against the oracle that rounds the same way, over several hundred cached keys (more than one pass of the
+    score loop, every lane of the 8-lane value groups), with the key range split over workgroups (B * heads = 4) and not (144);
+    a ragged batch (left padding), switching the format back and forth on one context (cached decode graphs are keyed by it)."""
+    from indextts_amd.gpt import UnifiedVoice
+    from oracle import gpt as og
+    cfg = GPTConfig(model_dim=64 * heads, heads=heads, layers=2, number_mel_codes=130, number_text_tokens=90, start_mel_token=128, stop_mel_token=129,
+                    max_mel_tokens=700, max_text_tokens=300, cond_latents=8)
+    w = weights.synth_gpt_weights(cfg, tag=f"t/gpt/kv16/{heads}")
+    w["mel_head.bias"][cfg.stop_mel_token] = -1e4          # never stop
+    uv = UnifiedVoice(w, cfg, device=device, kv_format="bf16")
+    assert uv.kv_format == "bf16" and uv.weight_format == "f32"
+    tw = {k: torch.from_numpy(v) for k, v in w.items()}
+    L, NEW = 290, 300 if B == 2 else 40
+    lat = torch.from_numpy(synth.uniform("t/gpt/kv16/lat", (B, cfg.cond_latents, cfg.model_dim), 0.5))
+    emo = torch.from_numpy(synth.uniform("t/gpt/kv16/emo", (B, cfg.model_dim), 0.3))
+    text = torch.from_numpy(synth.integers("t/gpt/kv16/text", (B, L), 2, cfg.number_text_tokens))
+    text[1, 23:] = cfg.stop_text_token
+    conds = og.conds_latent(tw, cfg, lat, emo)
+    codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, repetition_penalty=10.0)
+    with torch.no_grad():
+        ref16 = og.generate_greedy(tw, cfg, conds, text, NEW, 10.0, kv_round=True)
+        ref32 = og.generate_greedy(tw, cfg, conds, text, NEW, 10.0)
+    assert codes.shape[1] == NEW and np.array_equal(codes.cpu().numpy(), ref16.numpy())
+    uv.set_kv_format("f32")
+    codes32, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, repetition_penalty=10.0)
+    assert np.array_equal(codes32.cpu().numpy(), ref32.numpy())
+    uv.set_kv_format("bf16")
+    again, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, repetition_penalty=10.0)
+    assert torch.equal(again, codes)
+
+
+def test_bf16_kv_cache_beam_sample_vs_oracle(device):
+    """Beam search and beam-sample (the reference's default mode) on the bf16 cache: the KV rows of the generated positions are
+    re-indexed by beam ancestry in 16-byte granules of the bf16 layout -- tokens bit-exact against oracle.gpt.generate_beam with kv_round."""
+    from indextts_amd.gpt import UnifiedVoice
+    from oracle import gpt as og
+    cfg = GPTConfig(model_dim=128, heads=2, layers=2, number_mel_codes=70, number_text_tokens=40, start_mel_token=68, stop_mel_token=69,
+                    max_mel_tokens=60, max_text_tokens=30, cond_latents=4)
+    w = weights.synth_gpt_weights(cfg, tag="t/gpt/kv16/beam")
+    w["mel_head.bias"][cfg.stop_mel_token] += 3.0
+    uv = UnifiedVoice(w, cfg, device=device, kv_format="bf16")
+    tw = {k: torch.from_numpy(v) for k, v in w.items()}
+    B, L, NEW, NB = 2, 7, 24, 3
+    lat = torch.from_numpy(synth.uniform("t/gpt/kv16/beam/lat", (B, cfg.cond_latents, cfg.model_dim), 0.5))
+    emo = torch.from_numpy(synth.uniform("t/gpt/kv16/beam/emo", (B, cfg.model_dim), 0.3))
+    text = torch.from_numpy(synth.integers("t/gpt/kv16/beam/text", (B, L), 2, cfg.number_text_tokens))
+    g = torch.Generator().manual_seed(11)
+    noise = torch.empty(NEW, B, NB * cfg.number_mel_codes).exponential_(1.0, generator=g)
+    for do_sample in (True, False):
+        codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, num_beams=NB, do_sample=do_sample, top_p=0.8, top_k=30,
+                                       temperature=0.8, repetition_penalty=10.0, length_penalty=0.0, exp_noise=noise)
+        with torch.no_grad():
+            want = og.generate_beam(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, NEW, noise, num_beams=NB, do_sample=do_sample, kv_round=True)
+        got = codes.cpu().numpy()
+        assert got.shape == tuple(want.shape) and np.array_equal(got, want.numpy()), do_sample

@@ -105,3 +105,27 @@ def test_warp_scores_edge_cases():
     assert torch.isfinite(w).sum() >= 1 and torch.isfinite(w[0, 1:3]).any()
     assert torch.equal(og.warp_scores(s.clone(), 1.0, 0, 1.0), s)
     assert torch.allclose(og.warp_scores(s.clone(), 0.5, 0, 1.0), s / 0.5)
+
+
+def test_kv_round_mode_rounds_keys_and_values_once_and_only_them(golden_dir):
+    """The bf16 KV-cache mode of the oracle (gpt2_stack(kv_round=True), the checker of idxtts_gpt_set_kv_format): every cached key /
+    value is a bf16 number (16 low mantissa bits zero), a cached step reads exactly what the prefill stored, the logits move by no
+    more than bf16 rounding of the keys and values can explain, and the default mode is untouched (HF fixture above)."""
+    g, cfg, w = _setup(golden_dir)
+    B, S = 2, 9
+    emb = torch.from_numpy(synth.uniform("t/oracle/kvround/emb", (B, S, cfg.model_dim), 1.0))
+    with torch.no_grad():
+        h32, past32 = og.gpt2_stack(w, cfg, emb[:, :-1])
+        h16, past16 = og.gpt2_stack(w, cfg, emb[:, :-1], kv_round=True)
+        for (k, v), (k0, v0) in zip(past16, past32):
+            for t, t0 in ((k, k0), (v, v0)):
+                bits = t.contiguous().view(torch.int32)
+                assert int((bits & 0xFFFF).abs().max()) == 0
+                assert (t - t0).abs().max().item() <= 2.0 ** -8 * t0.abs().max().item()
+        step16, past16b = og.gpt2_stack(w, cfg, emb[:, -1:], past=past16, kv_round=True)
+        full16, _ = og.gpt2_stack(w, cfg, emb, kv_round=True)
+    for (k, v), (kp, vp) in zip(past16b, past16):
+        assert torch.equal(k[:, :, :S - 1], kp) and torch.equal(v[:, :, :S - 1], vp)
+    np.testing.assert_allclose(step16[:, 0].numpy(), full16[:, -1].numpy(), rtol=0, atol=2e-5)       # cached step == uncached row
+    d = (h16 - h32).abs().max().item()
+    assert 0 < d <= 0.05 * h32.abs().max().item()
