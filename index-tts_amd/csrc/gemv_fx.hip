@@ -502,7 +502,7 @@ void gemv_fx_plan(int N, int K, int rows, int* ntw, int* kw) {
   *kw = k;
   // Two column tiles per wave (one activation fragment feeds both) exactly when that turns a two-round launch into one
   // round of <= 256 workgroups (c_fc: 320 tiles); measured per shape in profiles/r01_gemv_probe.txt
-  *ntw = (MT == 1 && ntiles > 256 && cdiv(ntiles, 2) <= 256) ? 2 : 1;
+  *ntw = (MT <= 2 && ntiles > 256 && cdiv(ntiles, 2) <= 256) ? 2 : 1;
 }
 
 int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t stream) {
@@ -525,6 +525,8 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
   p.cps = cdiv(p.kc16, p.kw * p.ksb);
   p.act = a.act; p.dbg = a.dbg;
   const int MT = cdiv(a.rows, 16);
+  const bool single = p.cps <= 5;
+  if (MT == 2 && !single) ntw = 1;      // two column tiles per wave at 17..32 rows exist in the one-batch form only
   const int nacc = MT * ntw;
   const int threads = std::max(64 * p.kw, 256 * nacc);      // one epilogue thread per output element of the workgroup
   IDX_CHECK(threads <= 1024, "workgroup size");
@@ -556,11 +558,16 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
     else LAUNCH_W(MTV, NTWV, SG, WFMT_F32)                                                                                \
   }
   const bool r4 = a.rows <= 4;
-  const bool single = p.cps <= 5;
   if (MT == 1 && ntw == 2 && single) LAUNCH(1, 2, true)
   else if (MT == 1 && ntw == 2) LAUNCH(1, 2, false)
   else if (MT == 1 && single) LAUNCH(1, 1, true)
   else if (MT == 1) LAUNCH(1, 1, false)
+  // 17..48 rows (coalesced decodes, 16 utterances x 3 beams): the one-batch form as well -- all five chunks of a wave's K-slice in
+  // flight at once (10 + 20 MT VGPRs of operands: one workgroup per CU); the two-buffer form with 1-2 chunks per batch measured
+  // 14.6 / 16.5 us per launch at 32 / 48 rows against 7.8 at 16 (profiles/README.md "Round 3")
+  else if (MT == 2 && ntw == 2 && single) LAUNCH(2, 2, true)
+  else if (MT == 2 && single) LAUNCH(2, 1, true)
+  else if (MT == 3 && single) LAUNCH(3, 1, true)
   else if (MT == 2) LAUNCH(2, 1, false) else if (MT == 3) LAUNCH(3, 1, false) else LAUNCH(4, 1, false)
 #undef LAUNCH_R
 #undef LAUNCH_W
