@@ -426,8 +426,9 @@ def self_launch(argv, n_gpus: int) -> int:
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8, help="timed steps (default 8: the pipeline's fill and drain are inside the timed region, "
+                                                          "so very short runs under-state the steady rate)")
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--prompt-seconds", type=float, default=15.0, help="prompt / infer_default workloads: length of the speaker and emotion prompts")
     ap.add_argument("--workload", default="pipeline", choices=["pipeline", "vocoder", "longform", "prompt", "infer_default"],
                     help="pipeline = BASELINE configs[2] (the metric's configuration); vocoder = configs[1]; longform = configs[4]: ONE "
