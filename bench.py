@@ -43,7 +43,7 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 # the rows of profiles/rNN_*_kernel_stats.csv whose name contains it.
 MFMA_KERNELS = ("conv1d_mfma_kernel", "conv1d_bf16x3_kernel", "gemm_tn_kernel", "gemm_bf16x3", "flash_attn")
 SPLIT_BF16_KERNELS = ("conv1d_bf16x3_kernel", "gemm_bf16x3", "flash_attn_bf16x3_kernel", "flash_attn_planes_kernel")
-DECODE_KERNELS = ("gemv_fx_kernel", "gemv_fx_combine_kernel", "decode_attn_kernel", "sample_greedy_kernel", "sample_warp_kernel", "embed_step_kernel",
+DECODE_KERNELS = ("gemv_fx_kernel", "gemv_fx_combine_kernel", "decode_attn_kernel", "decode_attn16_kernel", "sample_greedy_kernel", "sample_warp_kernel", "embed_step_kernel",
                   "advance_state_kernel", "beam_")
 
 

@@ -13,7 +13,7 @@ import sys
 FAMILIES = ["conv1d_bf16x3_kernel<2, 2, 2, 2>", "conv1d_bf16x3_kernel<3, 2, 1, 4>", "conv1d_bf16x3_kernel<2, 2, 1, 4>", "conv1d_bf16x3_kernel<1, 4, 1, 4>",
             "conv1d_mfma_kernel<2, 2, 2, 2>", "conv1d_mfma_kernel<3, 2, 1, 4>", "conv1d_mfma_kernel<2, 2, 1, 4>", "conv1d_mfma_kernel<1, 4, 1, 4>",
             "gemm_bf16x3_big_kernel<2>", "gemm_bf16x3_big_kernel<4>", "gemm_bf16x3_v2_kernel", "gemm_bf16x3_kernel", "gemm_tn_kernel",
-            "gemv_fx_combine_kernel", "gemv_fx_kernel", "decode_attn_kernel", "flash_attn_planes_kernel", "flash_attn_bf16x3_kernel",
+            "gemv_fx_combine_kernel", "gemv_fx_kernel", "decode_attn_kernel", "decode_attn16_kernel", "flash_attn_planes_kernel", "flash_attn_bf16x3_kernel",
             "flash_attn_f32_kernel", "aa_act_kernel", "ada_rms_planes512_kernel", "rows_norm_kernel", "split_planes_kernel", "sample_greedy_kernel",
             "conv_post_kernel", "cfm_pack_kernel", "embed_step_kernel"]
 CATEGORY = [(f, f) for f in FAMILIES]
