@@ -306,7 +306,29 @@ def build_pipeline(args, world, rank, dev):
             cdt = time.perf_counter() - c0
         caudio = r["wav"].shape[-1] / cfg.bigvgan.sampling_rate
         wavs, mid = tts.synthesize_batch(ctext, cond_dev, max_mel_tokens=Mc, noise=cnoise.to(dev), return_intermediates=True)
-        codes_equal = bool(np.array_equal(mid["codes"][0].cpu().numpy(), r["codes"][0].numpy()))
+        got, ref = mid["codes"][0].cpu().numpy(), r["codes"][0].numpy()
+        codes_equal = bool(np.array_equal(got, ref))
+        extra = {}
+        if not codes_equal:
+            # Reduced-precision STORAGE (bf16 KV cache: a one-ulp difference between the two fp32 summation orders can move a key's bf16
+            # rounding by 2^-9) can flip a near-tie of the argmax; from there the two sequences are different utterances.  Report where
+            # and how close the tie was, and compare everything behind the decode on the ORACLE's codes.
+            n = min(len(got), len(ref))
+            sdiff = int(np.nonzero(got[:n] != ref[:n])[0][0]) if n and (got[:n] != ref[:n]).any() else n
+            from oracle import gpt as og
+            with torch.no_grad():
+                conds = og.conds_latent(twg, cfg.gpt, cond0.spk_cond_latent, cond0.emo_vec)
+                _, lg = og.generate_greedy(twg, cfg.gpt, conds, ctext, sdiff + 1, 10.0, return_logits=True, kv_round=kv16)
+                fake = og.prepare_gpt_inputs(twg, cfg.gpt, conds, ctext)[0]
+                ids = torch.cat([fake, torch.from_numpy(ref[:sdiff].astype(np.int64))[None]], dim=1)
+                sc = og.repetition_penalty(ids, lg[:, sdiff].float(), 10.0)[0]
+            margin = float(sc[int(ref[sdiff])] - sc[int(got[sdiff])]) if sdiff < n else None
+            extra = {"codes_first_difference_step": sdiff, "oracle_score_margin_at_that_step": margin, "oracle_score_std": float(sc.std()),
+                     "stages_behind_the_decode_compared_on": "the oracle's codes (teacher-forced)"}
+            st = tts.gpt_stage(ctext, cond_dev, max_mel_tokens=Mc, codes=r["codes"])
+            wavs, mid = tts.acoustic_stage(st, noise=cnoise.to(dev), return_intermediates=True)
+            log(f"[bench] cpu oracle: greedy codes differ from step {sdiff} of {n} on (oracle's score margin between the two tokens there: {margin:.3e}, "
+                f"score std {float(sc.std()):.2f}); comparing the stages behind the decode on the oracle's codes")
         mel_l1 = (mid["mel"][0].cpu() - r["mel"][0]).abs().mean().item()
         wav_err = (wavs[0].cpu() - r["wav"]).abs().max().item() / 32767.0
         log(f"[bench] cpu oracle: {caudio:.2f}s audio in {cdt:.1f}s; gpu-vs-cpu on that utterance: greedy codes equal={codes_equal}, "
@@ -315,6 +337,7 @@ def build_pipeline(args, world, rank, dev):
                 "sample": f"oracle/pipeline.py (fp32 torch CPU): 1 utterance, {Lc} text tokens, {Mc} codes ({caudio:.2f} s audio), "
                           f"Tp={Tp}, {cfg.diffusion_steps} CFM steps, full-size weights (the B = 16 x 512-code batch of the GPU run would "
                           f"take the oracle ~20 minutes: BASELINE.md 3's B = 16 leg does not fit the bounded sample)",
+                **extra,
                 "greedy_codes_equal_vs_gpu": codes_equal, "mel_l1_vs_gpu": mel_l1, "wav_max_abs_diff_vs_gpu_fullscale": wav_err}
 
     desc = {"workload": f"{'configs[4] (long-form, emotion vector, fp8 GPT weights, graph-replayed decode)' if args.longform else 'configs[2]'}: IndexTTS-2 full pipeline (gpt 472M + s2mel 98M + BigVGAN 112M params), batch {B} utterances per "

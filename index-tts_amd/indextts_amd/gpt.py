@@ -82,6 +82,7 @@ class UnifiedVoice:
         import threading
         self._ws = None
         self._ws_lock = threading.Lock()
+        self._conds_cache = {}
         self.stop_mel_token = cfg.stop_mel_token
         self.start_mel_token = cfg.start_mel_token
         self.accel_engine = self       # the reference selects `self.accel_engine.generate` (model_v2.py:871)
@@ -157,10 +158,24 @@ class UnifiedVoice:
     def conds_latent(self, speech_conditioning_latent: torch.Tensor, emo_vec: torch.Tensor) -> torch.Tensor:
         """cat(latent + emo_vec, speed_emb(1), speed_emb(0)) -> [B, 34, d]   (model_v2.py:830-834)."""
         lat = speech_conditioning_latent.to(self.device, torch.float32)
+        ev = emo_vec.to(self.device, torch.float32)
         B = lat.shape[0]
+        # One prompt is decoded many times (segments, batches, serving lanes): the sum is kept per (latent, emotion vector) storage so that
+        # no torch elementwise kernel runs on a decode lane's stream per call (ADVICE r2: torch's own fp32 kernels beside bf16 MFMAs are
+        # outside the NOPK build switch); a consumer on another stream waits for the event of the stream that produced the entry.
+        key = (lat.data_ptr(), lat._version, tuple(lat.shape), tuple(lat.stride()), ev.data_ptr(), ev._version, tuple(ev.shape), tuple(ev.stride()))
+        hit = self._conds_cache.get(key)
+        if hit is not None:
+            torch.cuda.current_stream(self.device).wait_event(hit[1])
+            return hit[0]
         se = self.speed_emb
-        return torch.cat([lat + emo_vec.to(self.device, torch.float32)[:, None, :], se[1].expand(B, 1, -1),
-                          se[0].expand(B, 1, -1)], dim=1).contiguous()
+        conds = torch.cat([lat + ev[:, None, :], se[1].expand(B, 1, -1), se[0].expand(B, 1, -1)], dim=1).contiguous()
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        if len(self._conds_cache) >= 16:
+            self._conds_cache.pop(next(iter(self._conds_cache)))
+        self._conds_cache[key] = (conds, done, lat.untyped_storage(), ev.untyped_storage())      # the storages are kept alive: a data_ptr is not reused
+        return conds
 
     def prepare_gpt_inputs(self, conditional_latents: torch.Tensor, text_inputs: torch.Tensor):
         """model_v2.py:725-794 -> (fake_inputs [B,P+1], inputs_embeds [B,P,d] on the GPU, attention_mask [B,P+1])."""

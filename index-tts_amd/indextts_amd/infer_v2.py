@@ -212,9 +212,11 @@ class IndexTTS2:
         return time.perf_counter()
 
     def gpt_stage(self, text_tokens: torch.Tensor, cond: PromptConditioning, max_mel_tokens: int = 1500,
-                  repetition_penalty: float = 10.0, sampling: Optional[dict] = None, sync_timers: bool = False) -> dict:
+                  repetition_penalty: float = 10.0, sampling: Optional[dict] = None, sync_timers: bool = False,
+                  codes: Optional[torch.Tensor] = None) -> dict:
         """Decode + stop-token trim + latent pass (infer_v2.py:732-828) on the current stream; returns the state
-        acoustic_stage consumes (device tensors + host lengths)."""
+        acoustic_stage consumes (device tensors + host lengths).  `codes` [B, n] (optional): take these codes instead of decoding --
+        the rest of the flow on a given code sequence (parity checks feed the reference's codes through the stages behind the decode)."""
         dev = self.device
         c = cond.to(dev)
         B = text_tokens.shape[0]
@@ -224,8 +226,11 @@ class IndexTTS2:
         emo = c.emo_vec.expand(B, -1) if c.emo_vec.shape[0] == 1 else c.emo_vec
         gen = dict(sampling) if sampling else {"do_sample": False}
         gen.setdefault("num_beams", 1)
-        codes, _ = self.gpt.inference_speech(lat, text_tokens, emo_vec=emo, max_generate_length=max_mel_tokens,
-                                             repetition_penalty=repetition_penalty, **gen)
+        if codes is None:
+            codes, _ = self.gpt.inference_speech(lat, text_tokens, emo_vec=emo, max_generate_length=max_mel_tokens,
+                                                 repetition_penalty=repetition_penalty, **gen)
+        else:
+            codes = torch.as_tensor(codes).to(dev, torch.long)
         t1 = self._tick(sync_timers)
         times["gpt_gen_time"] = t1 - t0
         # trim at the first stop token (infer_v2.py:795-807)
