@@ -320,7 +320,7 @@ static int launch_conv16(const ConvWeights& w, const ConvArgs& a, hipStream_t st
   const double flops = 2.0 * cout * w.Cin * taps * tout;
   const double bytes = 4.0 * ((double)a.B * w.Cin * a.T + cout * tout * (1.0 + (a.res ? 1.0 : 0.0) + (a.accum ? 1.0 : 0.0)) +
                               cout * w.Cin * (w.ups > 1 ? 2.0 * w.ups : (double)w.K));
-  static const int cat = prof_register(("conv1d_bf16x3_kernel<" + std::to_string(TM) + ", " + std::to_string(TN) + ", " + std::to_string(WGM) + ", " + std::to_string(WGN) + ">").c_str());
+  static const int cat = prof_register(("conv1d_bf16x3_kernel<" + std::to_string(TM) + ", " + std::to_string(TN) + ", " + std::to_string(WGM) + ", " + std::to_string(WGN) + (K1 ? ", true>" : ", false>")).c_str());
   ProfScope prof(cat, stream, flops, bytes);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p);
   IDX_LAUNCH_CHECK();

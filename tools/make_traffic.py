@@ -10,7 +10,8 @@ import json
 import sys
 
 # bench.py's kernel families are kernel function names (csrc/prof.h); families that keep their template arguments first
-FAMILIES = ["conv1d_bf16x3_kernel<2, 2, 2, 2>", "conv1d_bf16x3_kernel<3, 2, 1, 4>", "conv1d_bf16x3_kernel<2, 2, 1, 4>", "conv1d_bf16x3_kernel<1, 4, 1, 4>",
+FAMILIES = ["conv1d_bf16x3_kernel<2, 2, 2, 2, false>", "conv1d_bf16x3_kernel<3, 2, 1, 4, false>", "conv1d_bf16x3_kernel<2, 2, 1, 4, false>", "conv1d_bf16x3_kernel<1, 4, 1, 4, false>",
+            "conv1d_bf16x3_kernel<2, 2, 2, 2, true>", "conv1d_bf16x3_kernel<3, 2, 1, 4, true>", "conv1d_bf16x3_kernel<2, 2, 1, 4, true>", "conv1d_bf16x3_kernel<1, 4, 1, 4, true>",
             "conv1d_mfma_kernel<2, 2, 2, 2>", "conv1d_mfma_kernel<3, 2, 1, 4>", "conv1d_mfma_kernel<2, 2, 1, 4>", "conv1d_mfma_kernel<1, 4, 1, 4>",
             "gemm_bf16x3_big_kernel<2>", "gemm_bf16x3_big_kernel<4>", "gemm_bf16x3_v2_kernel", "gemm_bf16x3_kernel", "gemm_tn_kernel",
             "gemv_fx_combine_kernel", "gemv_fx_kernel", "decode_attn_kernel", "decode_attn16_kernel", "flash_attn_planes_kernel", "flash_attn_bf16x3_kernel",
