@@ -246,8 +246,10 @@ def build_pipeline(args, world, rank, dev):
     from indextts_amd.serving import BatchPipeline
     lanes = max(1, args.decode_lanes)
     pipe = None if args.no_overlap else BatchPipeline(tts, decode_lanes=lanes, acoustic_workers=max(1, args.acoustic_workers),
-                                                      coalesce=max(1, args.coalesce), lane_priority=args.lane_priority)
-    in_flight = lanes * max(1, args.coalesce) + 1     # batches submitted and not yet retired: every lane full plus one waiting
+                                                      coalesce=max(1, args.coalesce), lane_priority=args.lane_priority,
+                                                      acoustic_coalesce=max(1, args.acoustic_coalesce))
+    # batches submitted and not yet retired: every lane full plus what one acoustic batch takes
+    in_flight = lanes * max(1, args.coalesce) + max(1, args.acoustic_coalesce)
     if pipe is not None and args.trace_jobs:
         pipe.trace = []
     pending = []
@@ -350,7 +352,9 @@ def build_pipeline(args, world, rank, dev):
     desc["step_overlap"] = ("none" if args.no_overlap else
                             f"software pipeline across steps: {lanes} decode chain(s) in flight (one stream + host thread each"
                             + (f", a free lane decodes up to {args.coalesce} waiting 16-utterance requests as one batch" if args.coalesce > 1 else "")
-                            + f"), {max(1, args.acoustic_workers)} s2mel+vocoder stage(s) at a time behind them; every batch inside the timed region")
+                            + f"), {max(1, args.acoustic_workers)} s2mel+vocoder stage(s) at a time behind them"
+                            + (f" (a free one takes up to {args.acoustic_coalesce} decoded requests as one batch)" if args.acoustic_coalesce > 1 else "")
+                            + "; every batch inside the timed region")
     step.flush = (lambda: None) if args.no_overlap else flush
     nref = 16 if world > 1 else len(text)        # multi-rank: a shard goes through the pipeline in batches of 16
     step.reference = lambda: tts.synthesize_batch(text[:nref], cond_dev, max_mel_tokens=M, noise=noise[:nref])[0]
@@ -468,6 +472,7 @@ def main() -> int:
                     help="pipeline workload: decode chains of consecutive batches in flight at once (each on its own stream and host thread)")
     ap.add_argument("--acoustic-workers", type=int, default=1, help="pipeline workload: s2mel + vocoder stages of different batches in flight at once")
     ap.add_argument("--lane-priority", default="high", choices=["high", "normal"], help="pipeline workload: HIP stream priority of the decode lanes")
+    ap.add_argument("--acoustic-coalesce", type=int, default=1, help="pipeline workload: a free acoustic worker takes up to this many decoded requests as one s2mel + vocoder batch")
     ap.add_argument("--coalesce", type=int, default=1,
                     help="pipeline workload: a free decode lane takes up to this many waiting 16-utterance requests and decodes them as one batch")
     ap.add_argument("--s2mel-overlap", action="store_true",

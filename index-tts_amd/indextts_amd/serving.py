@@ -7,7 +7,8 @@ and fill the chip.  `BatchPipeline` keeps `decode_lanes` decode chains running a
 own host thread (the C call releases the GIL), with its own KV-cache workspace -- and runs the acoustic stages on
 `acoustic_workers` further streams.
 
-`coalesce` > 1 is dynamic batching of the decode: a lane that becomes free takes up to `coalesce` waiting requests of the same
+`acoustic_coalesce` > 1 lets a free acoustic worker take that many decoded requests (same prompt, explicit CFM noise) as ONE s2mel +
+vocoder batch; `coalesce` > 1 is dynamic batching of the decode: a lane that becomes free takes up to `coalesce` waiting requests of the same
 prompt and text width and decodes them as ONE batch (a decode step streams the 965 MB of GPT weights once whatever the number of rows, so two
 16-utterance requests decoded together cost little more than one), then hands every request's rows to its own acoustic job.
 
@@ -49,14 +50,17 @@ class _Request:
 
 
 class BatchPipeline:
-    def __init__(self, tts, decode_lanes: int = 3, acoustic_workers: int = 1, coalesce: int = 1, lane_priority: str = "high"):
-        if decode_lanes < 1 or acoustic_workers < 1 or coalesce < 1:
-            raise ValueError("decode_lanes, acoustic_workers and coalesce must be >= 1")
+    def __init__(self, tts, decode_lanes: int = 3, acoustic_workers: int = 1, coalesce: int = 1, lane_priority: str = "high",
+                 acoustic_coalesce: int = 1):
+        if decode_lanes < 1 or acoustic_workers < 1 or coalesce < 1 or acoustic_coalesce < 1:
+            raise ValueError("decode_lanes, acoustic_workers, coalesce and acoustic_coalesce must be >= 1")
         self.tts = tts
         self.device = torch.device(tts.device)
         self.decode_lanes = decode_lanes
         self.acoustic_workers = acoustic_workers
         self.coalesce = coalesce
+        self.acoustic_coalesce = acoustic_coalesce
+        self._aq = collections.deque()         # decoded requests waiting for an acoustic worker: (request, state)
         lo_pri, hi_pri = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
         self._pri = {"decode": hi_pri if lane_priority == "high" else lo_pri, "acoustic": lo_pri}
         self._tls = threading.local()          # one stream per worker THREAD: two jobs never share a stream (= a workspace)
@@ -125,28 +129,70 @@ class BatchPipeline:
                 n = max(st["code_lens"][a:b])
                 sub = {"cond": st["cond"], "B": b - a, "codes": st["codes"][a:b, :n].contiguous(), "code_lens": st["code_lens"][a:b],
                        "code_lens_t": st["code_lens_t"][a:b].clone(), "latent": st["latent"][a:b, :n].contiguous(), "times": dict(st["times"])}
-                self._acoustic.submit(self._acoustic_job, r, sub)
+                with self._qlock:
+                    self._aq.append((r, sub))
+                self._acoustic.submit(self._acoustic_drain)      # one drain per request: a drain that finds nothing (merged away) returns
                 a = b
         except BaseException as e:                  # noqa: BLE001 -- handed to the callers through their futures
             for r in group:
                 if not r.done.done():
                     r.done.set_exception(e)
 
-    def _acoustic_job(self, r: _Request, st: dict):
+    def _take_acoustic(self):
+        """Up to `acoustic_coalesce` decoded requests of one prompt, each with its own CFM noise (a merged draw would consume the
+        generator differently from the separate calls)."""
+        with self._qlock:
+            if not self._aq:
+                return []
+            group = [self._aq.popleft()]
+            while (len(group) < self.acoustic_coalesce and self._aq and group[0][0].noise is not None and self._aq[0][0].noise is not None
+                   and self._aq[0][0].cond is group[0][0].cond):
+                group.append(self._aq.popleft())
+            return group
+
+    @staticmethod
+    def _merge_states(group):
+        """Several decoded batches as ONE acoustic batch: rows are independent in s2mel and the vocoder (ragged lengths: every row is
+        padded at its own end), so stacking them only changes how the launches fill the chip.  (Measured neutral at configs[2]:
+        181.8 vs 182.3 audio-s/s, profiles/README.md "Round 3"; useful where single requests are small.)"""
+        sts = [st for _, st in group]
+        n = max(st["codes"].shape[1] for st in sts)
+        codes = torch.cat([torch.nn.functional.pad(st["codes"], (0, n - st["codes"].shape[1])) for st in sts])
+        latent = torch.cat([torch.nn.functional.pad(st["latent"], (0, 0, 0, n - st["latent"].shape[1])) for st in sts])
+        T = max(r.noise.shape[-1] for r, _ in group)
+        noise = torch.cat([torch.nn.functional.pad(r.noise, (0, T - r.noise.shape[-1])) for r, _ in group])
+        st = {"cond": sts[0]["cond"], "B": sum(st["B"] for st in sts), "codes": codes, "code_lens": [c for st in sts for c in st["code_lens"]],
+              "code_lens_t": torch.cat([st["code_lens_t"] for st in sts]), "latent": latent, "times": dict(sts[0]["times"])}
+        return st, noise
+
+    def _acoustic_drain(self):
+        group = self._take_acoustic()
+        if not group:
+            return
         try:
             torch.cuda.set_device(self.device)
             t0 = time.perf_counter()
             sa = self._stream("acoustic")
             with torch.cuda.stream(sa):
-                wavs = self.tts.acoustic_stage(st, noise=r.noise)
-                sa.synchronize()                 # the state's tensors may be released once this returns
-            for w in wavs:                        # allocated on the worker's stream, consumed on the caller's
-                w.record_stream(r.caller)
+                if len(group) == 1:
+                    st, noise = group[0][1], group[0][0].noise
+                else:
+                    st, noise = self._merge_states(group)
+                wavs = self.tts.acoustic_stage(st, noise=noise)
+                sa.synchronize()                 # the states' tensors may be released once this returns
             if self.trace is not None:
                 self.trace.append(("acoustic", t0, time.perf_counter(), st["B"]))
-            r.done.set_result(wavs)
+            a = 0
+            for r, sub in group:
+                mine = wavs[a:a + sub["B"]]
+                a += sub["B"]
+                for w in mine:                    # allocated on the worker's stream, consumed on the caller's
+                    w.record_stream(r.caller)
+                r.done.set_result(mine)
         except BaseException as e:                  # noqa: BLE001
-            r.done.set_exception(e)
+            for r, _ in group:
+                if not r.done.done():
+                    r.done.set_exception(e)
 
     def close(self):
         self._lanes.shutdown(wait=True)

@@ -9,11 +9,11 @@ from indextts_amd.config import PipelineConfig
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("lanes,coalesce,workers", [(1, 1, 1), (3, 1, 1), (2, 3, 2), (1, 4, 1)])
-def test_batch_pipeline_equals_sequential(device, lanes, coalesce, workers):
+@pytest.mark.parametrize("lanes,coalesce,workers,acoal", [(1, 1, 1, 1), (3, 1, 1, 1), (2, 3, 2, 1), (1, 4, 1, 1), (3, 1, 1, 2), (2, 2, 1, 3)])
+def test_batch_pipeline_equals_sequential(device, lanes, coalesce, workers, acoal):
     """coalesce > 1: a free lane decodes several waiting requests (different widths and row counts here) as ONE batch and hands each
-    request's rows to its own acoustic job -- the kernels treat rows independently, so every request still equals its own
-    sequential call bit for bit."""
+    request's rows on; acoustic_coalesce > 1: a free acoustic worker takes several decoded requests as ONE s2mel + vocoder batch --
+    the kernels treat rows independently, so every request still equals its own sequential call bit for bit."""
     from indextts_amd.infer_v2 import IndexTTS2, PromptConditioning
     from indextts_amd.serving import BatchPipeline
     cfg = PipelineConfig.tiny()
@@ -36,14 +36,14 @@ def test_batch_pipeline_equals_sequential(device, lanes, coalesce, workers):
     # between the exact-fp32 and the split-bf16 kernel (a real utterance is hundreds of rows on its own): the merged cases run in
     # the exact mode, where kernel selection does not depend on the row count.
     mode = _lib.get_gemm_mode()
-    if coalesce > 1:
+    if coalesce > 1 or acoal > 1:
         _lib.set_gemm_mode(_lib.GEMM_F32)
     try:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             want = [tts.synthesize_batch(t, cond, max_mel_tokens=M, noise=n) for t, n in zip(texts, noises)]
             torch.cuda.synchronize()
-            with BatchPipeline(tts, decode_lanes=lanes, coalesce=coalesce, acoustic_workers=workers) as pipe:
+            with BatchPipeline(tts, decode_lanes=lanes, coalesce=coalesce, acoustic_workers=workers, acoustic_coalesce=acoal) as pipe:
                 futs = [pipe.submit(t, cond, max_mel_tokens=M, noise=n) for t, n in zip(texts, noises)]
                 got = [f.result() for f in futs]
     finally:
