@@ -113,6 +113,11 @@ def roofline_from_profile(prof, steps, workload="pipeline", split_bf16=True, def
     return r
 
 
+def _lib_geometry():
+    from indextts_amd import _lib
+    return _lib.get_decode_geometry()
+
+
 def stage_rooflines(stages, prof, nprof, B, L, M, Tp, Tg, n_cfm, w_bytes_per_param, kv_bytes=4):
     """One roofline per stage of the step (the step's time is split three ways: HBM-bound decode, MFMA-bound s2mel and vocoder).
     Work units are SURVEY.md 8(d)'s: GPT decode bytes/step = W + B*S*2*24*1280*sizeof(kv), W = 482.76 M params; s2mel flops =
@@ -348,6 +353,7 @@ def build_pipeline(args, world, rank, dev):
                         + ("" if not compact else f", GPT linear weights stored as {args.gpt_weights} (rounded once at load; fp32 arithmetic)")
                         + ("" if not kv16 else ", KV cache stored as bf16 (keys / values rounded once when produced; fp32 arithmetic)"),
             "gpt_weights": args.gpt_weights, "gpt_kv_cache": tts.gpt.kv_format,
+            "decode_geometry": "narrow (512-thread GEMV workgroups)" if _lib_geometry() else "wide (1024-thread GEMV workgroups)",
             "batch_per_gpu": B, "text_tokens": L, "codes": M, "prompt_frames": Tp, "diffusion_steps": cfg.diffusion_steps}
     desc["step_overlap"] = ("none" if args.no_overlap else
                             f"software pipeline across steps: {lanes} decode chain(s) in flight (one stream + host thread each"
@@ -485,6 +491,9 @@ def main() -> int:
                     help="storage of the GPT linear weights: bf16 (default for the pipeline workload: what BASELINE configs[2] names), "
                          "fp8-e4m3 with a power-of-two scale per output channel (default for longform = configs[4]), or f32 (the reference's "
                          "own weights, bit for bit); arithmetic stays fp32; the CPU baseline / parity leg runs the same rounded model")
+    ap.add_argument("--decode-geometry", default="auto", choices=["auto", "wide", "narrow"],
+                    help="decode GEMVs as 1024-thread (wide) or 512-thread (narrow) workgroups (idxtts_set_decode_geometry): auto = narrow for the "
+                         "pipelined run, whose decode launches have to find room beside the acoustic stage's kernels, wide with --no-overlap")
     ap.add_argument("--gpt-kv", default=None, choices=["f32", "bf16"],
                     help="storage of the GPT's KV cache: default bf16 with compact weights (the reference's use_fp16 halves weights and cache "
                          "together), f32 with --gpt-weights f32; keys / values are rounded once when produced, arithmetic stays fp32, and the "
@@ -533,6 +542,8 @@ def main() -> int:
     _lib.load()
     _lib.set_gemm_mode(0 if args.gemm == "f32" else 1)
     _lib.set_s2mel_overlap(bool(args.s2mel_overlap))
+    narrow = args.decode_geometry == "narrow" or (args.decode_geometry == "auto" and args.workload == "pipeline" and not args.no_overlap)
+    _lib.set_decode_geometry(narrow)
     t0 = time.time()
     build = build_pipeline if args.workload == "pipeline" else (build_prompt_or_infer if side else build_vocoder)
     step, profiled, cpu_leg, stage_times_fn, audio_s_per_step_per_gpu, desc = build(args, world, rank, dev)

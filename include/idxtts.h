@@ -119,6 +119,13 @@ int idxtts_linear_fwd(const idxtts_linear* lin, const float* x, int ldx, float* 
  * reference).  The KV-cached greedy decode and its prefill are always exact fp32 (token indices are bit-exact in both modes). */
 int idxtts_set_gemm_mode(int mode);
 int idxtts_get_gemm_mode(void);
+/* Geometry of the decode step's GEMVs (5..16 rows, bf16 / fp8 weight streams): 0 (default) = 1024-thread workgroups, the fastest form
+ * for a decode that has the GPU to itself; 1 = 512-thread workgroups at <= 88 VGPRs, which fit into what ONE retiring workgroup of
+ * an s2mel / vocoder kernel frees on a CU: 7 % slower alone, but a serving loop that decodes beside the acoustic stages of other
+ * batches (indextts_amd/serving.py) gains 1.5 % (profiles/README.md "Round 3").  The two forms split K over a different number of
+ * waves, so results differ in the last bits: choose once per process, before generating (cached decode graphs carry the choice). */
+int idxtts_set_decode_geometry(int narrow);
+int idxtts_get_decode_geometry(void);
 /* The CFM solver (idxtts_s2mel_cfm) can evaluate the conditional and the null half of its stacked batch (flow_matching.py:91-103,
  * one DiT.forward on 2B rows there) as two chains of launches on two streams, the null half a few kernels behind: same kernels
  * on the same rows, bit-identical results, 9 % less time for a solver that has the device to itself (one half's HBM-bound

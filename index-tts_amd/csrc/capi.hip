@@ -639,6 +639,13 @@ int idxtts_set_gemm_mode(int mode) {
 
 int idxtts_get_gemm_mode(void) { return get_gemm_mode(); }
 
+int idxtts_set_decode_geometry(int narrow) {
+  set_decode_geometry(narrow);
+  return 0;
+}
+
+int idxtts_get_decode_geometry(void) { return get_decode_geometry(); }
+
 int idxtts_s2mel_set_overlap(int on) {
   set_s2mel_overlap(on);
   return 0;

@@ -56,6 +56,11 @@ struct GemvFXArgs {
 int gemv_fx_ksb(int N, int K);
 int gemv_fx_combine(const float* slab, int ksb, int rows, int N, const float* bias, const float* res, float* y, hipStream_t stream);
 void gemv_fx_plan(int N, int K, int rows, int* ntw, int* kw);
+// 0 (default): 16 waves x 5 chunks (1024 threads, 256 registers per SIMD); 1: the narrow form, 8 waves x 10 chunks (512 threads, <= 176
+// registers per SIMD: what ONE retiring workgroup of the acoustic stage's kernels frees on a CU) for 5..16 rows on bf16 / fp8 streams.
+// The two forms split K differently, so their results differ in the last bits: a process-wide choice, made before generating.
+void set_decode_geometry(int narrow);
+int get_decode_geometry();
 int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t stream);
 
 }  // namespace idxtts

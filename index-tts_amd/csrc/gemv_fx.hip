@@ -25,6 +25,8 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
+
 #include "gemv16.h"
 #include "prof.h"
 
@@ -225,12 +227,16 @@ template <> struct WRaw<WFMT_FP8> {
 // same exact fp32 products.  Block b = lane >> 2 multiplies x[row r][k = 4 (b >> 2) + s] (lane 4 b + r) by
 // w[k][n = 4 (b & 3) + c] (lane 4 b + c): the weight stream is read as it is, the activation fragment is read from the lane
 // that holds row (lane & 3), and the accumulator ends up as the 16x16 C layout with the four k-groups (lane >> 4) still to add.
-template <int MT, int NTW, bool SINGLE, int WT, bool R4>
-__global__ __launch_bounds__(1024) void gemv_fx_kernel(const GemvFXP p) {
+// UNS: chunks of the one-batch form.  5 = a K-slice per wave of 16 waves (1024 threads, <= 64 VGPRs: 256 registers per SIMD); 10 = the
+// NARROW geometry: 8 waves (512 threads) of 10 chunks each at <= 88 VGPRs -- 176 registers per SIMD, what ONE retiring workgroup of the
+// acoustic stage's GEMM / convolution / attention kernels (168 x 1 wave per SIMD) frees on a CU, so a decode launch beside them does
+// not have to wait until two of a CU's three workgroups have gone.
+template <int MT, int NTW, bool SINGLE, int WT, bool R4, int UNS = 5>
+__global__ __launch_bounds__(UNS == 10 ? 512 : 1024) void gemv_fx_kernel(const GemvFXP p) {
   static_assert(!R4 || MT == 1, "the 4-row form has one row tile");
   typedef typename WRaw<WT>::raw wraw_t;
   if (p.dbg & 8) return;      // tools/gemv_probe.hip: launch + dispatch cost of this geometry alone
-  constexpr int UN = FXCfg<MT, NTW, SINGLE>::UN;
+  constexpr int UN = SINGLE ? UNS : FXCfg<MT, NTW, SINGLE>::UN;
   constexpr int NB = SINGLE ? 1 : 2;
   constexpr int NACC = MT * NTW;
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -495,11 +501,18 @@ int gemv_fx_combine(const float* slab, int ksb, int rows, int N, const float* bi
   return 0;
 }
 
+// Process-wide geometry of the 5..16-row decode GEMVs on compact weight streams (include/idxtts.h::idxtts_set_decode_geometry).
+static std::atomic<int> g_decode_narrow{0};
+void set_decode_geometry(int narrow) { g_decode_narrow.store(narrow ? 1 : 0); }
+int get_decode_geometry() { return g_decode_narrow.load(); }
+static bool gemv_fx_narrow() { return g_decode_narrow.load() != 0; }
+
 void gemv_fx_plan(int N, int K, int rows, int* ntw, int* kw) {
   const int kc16 = cdiv(K, 16), ntiles = cdiv(N, 16), MT = cdiv(rows, 16);
   int k = 16;
   while (k > 1 && kc16 < k) k >>= 1;
   *kw = k;
+  if (gemv_fx_narrow() && MT == 1 && rows > 4 && kc16 % 80 == 0) { *kw = 8; *ntw = 1; return; }
   // Two column tiles per wave (one activation fragment feeds both) exactly when that turns a two-round launch into one
   // round of <= 256 workgroups (c_fc: 320 tiles); measured per shape in profiles/r01_gemv_probe.txt
   *ntw = (MT <= 2 && ntiles > 256 && cdiv(ntiles, 2) <= 256) ? 2 : 1;
@@ -525,6 +538,11 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
   p.cps = cdiv(p.kc16, p.kw * p.ksb);
   p.act = a.act; p.dbg = a.dbg;
   const int MT = cdiv(a.rows, 16);
+  const bool narrow = p.kw == 8 && p.cps == 10 && MT == 1 && a.rows > 4 && w.fmt != WFMT_F32 && gemv_fx_narrow();
+  if (p.kw == 8 && !narrow && gemv_fx_narrow() && MT == 1 && a.rows > 4 && cdiv(w.K, 16) % 80 == 0) {      // fp32 streams: the 16-wave form
+    p.kw = 16; p.cps = cdiv(p.kc16, p.kw * p.ksb);
+    ntw = (p.ntiles > 256 && cdiv(p.ntiles, 2) <= 256) ? 2 : 1;
+  }
   const bool single = p.cps <= 5;
   if (MT == 2 && !single) ntw = 1;      // two column tiles per wave at 17..32 rows exist in the one-batch form only
   const int nacc = MT * ntw;
@@ -546,6 +564,16 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
     }                                                                                                                     \
     hipLaunchKernelGGL((gemv_fx_kernel<MTV, NTWV, SG, WTV, R4V>), grid, dim3(threads), lds, stream, p);                   \
   }
+#define LAUNCH_N(WTV)                                                                                                     \
+  {                                                                                                                       \
+    static bool attr_set = false;                                                                                         \
+    if (!attr_set) {                                                                                                      \
+      IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_fx_kernel<1, 1, true, WTV, false, 10>),              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));                               \
+      attr_set = true;                                                                                                    \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((gemv_fx_kernel<1, 1, true, WTV, false, 10>), grid, dim3(threads), lds, stream, p);                \
+  }
 #define LAUNCH_W(MTV, NTWV, SG, WTV)                                                                                      \
   {                                                                                                                       \
     if (MTV == 1 && r4) LAUNCH_R(1, NTWV, SG, WTV, true)                                                                  \
@@ -558,6 +586,9 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
     else LAUNCH_W(MTV, NTWV, SG, WFMT_F32)                                                                                \
   }
   const bool r4 = a.rows <= 4;
+  if (narrow) {
+    if (w.fmt == WFMT_FP8) { LAUNCH_N(WFMT_FP8) } else { LAUNCH_N(WFMT_BF16) }
+  } else
   if (MT == 1 && ntw == 2 && single) LAUNCH(1, 2, true)
   else if (MT == 1 && ntw == 2) LAUNCH(1, 2, false)
   else if (MT == 1 && single) LAUNCH(1, 1, true)
@@ -569,6 +600,7 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
   else if (MT == 2 && single) LAUNCH(2, 1, true)
   else if (MT == 3 && single) LAUNCH(3, 1, true)
   else if (MT == 2) LAUNCH(2, 1, false) else if (MT == 3) LAUNCH(3, 1, false) else LAUNCH(4, 1, false)
+#undef LAUNCH_N
 #undef LAUNCH_R
 #undef LAUNCH_W
 #undef LAUNCH

@@ -58,7 +58,7 @@ struct GPTModel : ModelBase {
   // Instantiated decode-step graphs of greedy generations, keyed by everything the captured launches depend on (workspace
   // address and carve, batch, penalty): a server replaying the same shapes on the same stream re-captures nothing.
   struct GraphSlot {
-    void* ws = nullptr; size_t ws_bytes = 0; int B = 0, S = 0, max_new = 0; float penalty = 0.0f; int kv16 = 0;
+    void* ws = nullptr; size_t ws_bytes = 0; int B = 0, S = 0, max_new = 0; float penalty = 0.0f; int kv16 = 0, geom = 0;
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; unsigned long stamp = 0; bool in_use = false;
   };
   std::vector<GraphSlot> graph_cache;

@@ -459,7 +459,7 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
       std::lock_guard<std::mutex> l(graph_mu);
       for (size_t i = 0; i < graph_cache.size(); ++i) {
         GraphSlot& g = graph_cache[i];
-        if (!g.in_use && g.ws == ws && g.ws_bytes == ws_bytes && g.B == B && g.S == S && g.max_new == max_new && g.penalty == penalty && g.kv16 == kv_fmt) {
+        if (!g.in_use && g.ws == ws && g.ws_bytes == ws_bytes && g.B == B && g.S == S && g.max_new == max_new && g.penalty == penalty && g.kv16 == kv_fmt && g.geom == get_decode_geometry()) {
           g.in_use = true; g.stamp = ++graph_stamp; exec = g.exec; lease.m = this; lease.idx = (int)i;
           break;
         }
@@ -487,7 +487,7 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
           GraphSlot& g = graph_cache[slot];
           if (g.exec) (void)hipGraphExecDestroy(g.exec);
           if (g.graph) (void)hipGraphDestroy(g.graph);
-          g.ws = ws; g.ws_bytes = ws_bytes; g.B = B; g.S = S; g.max_new = max_new; g.penalty = penalty; g.kv16 = kv_fmt;
+          g.ws = ws; g.ws_bytes = ws_bytes; g.B = B; g.S = S; g.max_new = max_new; g.penalty = penalty; g.kv16 = kv_fmt; g.geom = get_decode_geometry();
           g.graph = gg.graph; g.exec = gg.exec; g.stamp = ++graph_stamp; g.in_use = true;
           gg.graph = nullptr; gg.exec = nullptr;
           lease.m = this; lease.idx = slot;

@@ -23,6 +23,8 @@ throughput as strict turns (3 decodes together, then their 3 acoustic stages: 16
 240-320 one-round workgroups waits for the 256x256-tile GEMMs of an acoustic stage to give CUs back anyway (their workgroups own
 a CU's whole register file) -- so there is one schedule: sharing.
 
+    _lib.set_decode_geometry(True)           # once per process, before generating: decode GEMVs as 512-thread workgroups, which find room
+                                             # beside the acoustic stage's kernels (+1.5 % here, 7 % slower for a decode alone)
     pipe = BatchPipeline(tts, decode_lanes=3)
     futs = [pipe.submit(text_k, cond, max_mel_tokens=..., noise=noise_k) for text_k in batches]
     wavs = [f.result() for f in futs]        # lists of [1, n] waveforms, as synthesize_batch returns them

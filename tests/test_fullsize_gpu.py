@@ -240,9 +240,17 @@ def test_bf16_weights_and_kv_cache_16_utterances_vs_oracle(device, full):
     for b in range(B):
         text[b, L - (b % 5) * 3:] = g.stop_text_token
     lat, emo = c.spk_cond_latent.expand(B, -1, -1), c.emo_vec.expand(B, -1)
-    codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, do_sample=False, num_beams=1, repetition_penalty=10.0)
     torch.set_num_threads(16)
     with torch.no_grad():
         ref = og.generate_greedy(tw, g, og.conds_latent(tw, g, lat, emo), text, NEW, 10.0, kv_round=True)
-    got = codes.cpu().numpy()
-    assert got.shape == tuple(ref.shape) and np.array_equal(got, ref.numpy())
+    from indextts_amd import _lib
+    assert _lib.get_decode_geometry() is False
+    try:
+        for narrow in (False, True):      # idxtts_set_decode_geometry: the 1024-thread GEMVs and the 512-thread ones a serving loop selects
+            _lib.set_decode_geometry(narrow)
+            assert _lib.get_decode_geometry() is narrow
+            codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, do_sample=False, num_beams=1, repetition_penalty=10.0)
+            got = codes.cpu().numpy()
+            assert got.shape == tuple(ref.shape) and np.array_equal(got, ref.numpy()), narrow
+    finally:
+        _lib.set_decode_geometry(False)
