@@ -3,6 +3,8 @@
 #   gpurun_out/<rnd>_pipeline_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the default configs[2] command, sequential steps
 #   gpurun_out/<rnd>_pipeline_pmc_{fetch,write}_size.json   separate --pmc passes (FETCH_SIZE / WRITE_SIZE), condensed
 #   gpurun_out/traffic_<rnd>.json                   HBM bytes per launch, gfx950 corrections applied (tools/make_traffic.py)
+# (--decode-geometry narrow: the geometry the default, pipelined bench run selects, so that the kernels and their average durations are the
+# ones of its roofline leg.)
 # The counter passes serialise every dispatch they collect (~5 ms each): the acoustic kernels are collected on the full
 # configs[2] step, the decode kernels (125 launches per token) on a 48-token run of the same batch -- their bytes per launch do
 # not depend on the number of tokens beyond the KV length, which the 48-token run under-states (noted in profiles/README.md).
@@ -20,7 +22,7 @@ ACOUSTIC='gemm_bf16x3|conv1d_|flash_attn|aa_act|ada_rms|rows_norm|split_planes|g
 DECODE='gemv_fx|decode_attn|sample_greedy|embed_step'
 if [ "$WHAT" = all ] || [ "$WHAT" = stats ]; then
   rm -rf /tmp/prof_ks
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-overlap > $OUT/${R}_prof_ks.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-overlap --decode-geometry narrow > $OUT/${R}_prof_ks.log 2>&1 || exit 1
   cp $(find /tmp/prof_ks -name "*kernel_stats.csv" | head -1) $OUT/${R}_pipeline_kernel_stats.csv
   rm -rf /tmp/prof_ks
   echo "kernel stats done"
@@ -29,9 +31,9 @@ if [ "$WHAT" = all ] || [ "$WHAT" = pmc ]; then
   for C in FETCH_SIZE WRITE_SIZE; do
     lc=$(echo $C | tr A-Z a-z)
     rm -rf /tmp/prof_a /tmp/prof_d
-    rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "$ACOUSTIC" --output-format csv -d /tmp/prof_a -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-overlap > $OUT/${R}_prof_${lc}_a.log 2>&1 || exit 1
+    rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "$ACOUSTIC" --output-format csv -d /tmp/prof_a -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-overlap --decode-geometry narrow > $OUT/${R}_prof_${lc}_a.log 2>&1 || exit 1
     echo "$C acoustic pass done"
-    rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "$DECODE" --output-format csv -d /tmp/prof_d -- python3 $ROOT/bench.py --steps 1 --warmup 0 --codes 48 --no-cpu-baseline --no-roofline --no-overlap > $OUT/${R}_prof_${lc}_d.log 2>&1 || exit 1
+    rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "$DECODE" --output-format csv -d /tmp/prof_d -- python3 $ROOT/bench.py --steps 1 --warmup 0 --codes 48 --no-cpu-baseline --no-roofline --no-overlap --decode-geometry narrow > $OUT/${R}_prof_${lc}_d.log 2>&1 || exit 1
     echo "$C decode pass done"
     mkdir -p /tmp/prof_m && rm -rf /tmp/prof_m/* && i=0
     for f in $(find /tmp/prof_a /tmp/prof_d -name "*_counter_collection.csv"); do i=$((i+1)); cp $f /tmp/prof_m/${i}_counter_collection.csv; done
