@@ -39,6 +39,10 @@ import torch.distributed as dist  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+# Implementation noise a decode mode may add to a logit against the fp32 CPU oracle running the same (rounded) model -- the bounds
+# tests/test_fullsize_gpu.py asserts (logit std ~ 1 on these random-init weights): fp32 KV cache = summation order only; bf16 KV cache =
+# a key / value whose fp32 value differs in the last bit between two summation orders may round to the other bf16 neighbour.
+LOGIT_NOISE_BOUND = {"f32": 4e-4, "bf16": 4e-3}
 # Kernel families are named after the kernel function they time, as rocprofv3 prints it (csrc/prof.h): a family's line below matches
 # the rows of profiles/rNN_*_kernel_stats.csv whose name contains it.
 MFMA_KERNELS = ("conv1d_mfma_kernel", "conv1d_bf16x3_kernel", "gemm_tn_kernel", "gemm_bf16x3", "flash_attn")
@@ -340,6 +344,33 @@ def build_pipeline(args, world, rank, dev):
         wav_err = (wavs[0].cpu() - r["wav"]).abs().max().item() / 32767.0
         log(f"[bench] cpu oracle: {caudio:.2f}s audio in {cdt:.1f}s; gpu-vs-cpu on that utterance: greedy codes equal={codes_equal}, "
             f"mel L1={mel_l1:.2e}, max|wav| diff={wav_err:.2e} (full scale)")
+        # What "greedy codes equal" can mean in this mode, measured (oracle/parity.py): the first PB utterances' prefixes decoded by the
+        # oracle, the HIP path TEACHER-FORCED on the oracle's codes (logit noise, argmax match rate, the oracle's margin wherever the
+        # argmax differs) and free-running (where it leaves the oracle's sequence) -- in the run's own mode and, when that stores the
+        # KV cache as bf16, in the exact mode (fp32 cache) as well.
+        from oracle import parity
+        PB = min(8, len(text))
+        lat, emo = cond0.spk_cond_latent.expand(PB, -1, -1).contiguous(), cond0.emo_vec.expand(PB, -1).contiguous()
+        par, own = {}, tts.gpt.kv_format
+        c1 = time.perf_counter()
+        for mode in ([own] + (["f32"] if own == "bf16" else [])):
+            tts.gpt.set_kv_format(mode)
+            pr = parity.decode_parity(tts.gpt, twg, cfg.gpt, lat, emo, text[:PB, :Lc].clone(), Mc)
+            bound = LOGIT_NOISE_BOUND[mode]
+            pr["logit_bound"] = bound
+            pr["within_bound"] = bool(pr["max_abs_logit_diff"] <= bound and pr["worst_oracle_margin_at_a_mismatch"] <= 2 * bound
+                                      and pr["first_difference_step_free_running"] == pr["first_mismatch_step_teacher_forced"])
+            par[mode] = pr
+            log(f"[bench] decode parity, KV {mode}: {PB} utterances x {pr['steps']} steps teacher-forced on the oracle's codes: max |dlogit| "
+                f"{pr['max_abs_logit_diff']:.2e} (bound {bound:.0e}, logit std {pr['logit_std']:.2f}), argmax match rate {pr['codes_match_rate_teacher_forced']:.4f}, "
+                f"{len(pr['mismatching_steps'])} differing step(s), worst oracle margin there {pr['worst_oracle_margin_at_a_mismatch']:.2e}; free-running: first "
+                f"difference per utterance {pr['first_difference_step_free_running']}; within bound: {pr['within_bound']}")
+        tts.gpt.set_kv_format(own)
+        extra["decode_parity"] = par
+        extra["decode_parity_seconds"] = round(time.perf_counter() - c1, 1)
+        extra["codes_match_rate"] = par[own]["codes_match_rate_teacher_forced"]
+        extra["codes_match_rate_note"] = (f"{PB} utterances x {par[own]['steps']} steps, HIP decode teacher-forced on the oracle's codes (KV {own}); "
+                                          "free-running prefix match rate and the exact mode under decode_parity")
         return {"value": round(caudio / cdt, 4), "unit": "audio_s/s", "cores": cores, "kind": "port",
                 "sample": f"oracle/pipeline.py (fp32 torch CPU): 1 utterance, {Lc} text tokens, {Mc} codes ({caudio:.2f} s audio), "
                           f"Tp={Tp}, {cfg.diffusion_steps} CFM steps, full-size weights (the B = 16 x 512-code batch of the GPU run would "
@@ -366,6 +397,7 @@ def build_pipeline(args, world, rank, dev):
     step.reference = lambda: tts.synthesize_batch(text[:nref], cond_dev, max_mel_tokens=M, noise=noise[:nref])[0]
     step.flushed = flushed
     step.pipe = pipe
+    step.tts = tts
     return step, profiled, cpu_leg, stage_times, audio_s, desc
 
 
@@ -474,6 +506,7 @@ def main() -> int:
     ap.add_argument("--cpu-codes", type=int, default=96, help="codes of the bounded CPU-baseline utterance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-exact-mode", action="store_true", help="pipeline workload: skip the second timed run with the fp32 KV cache")
     ap.add_argument("--decode-lanes", type=int, default=3,
                     help="pipeline workload: decode chains of consecutive batches in flight at once (each on its own stream and host thread)")
     ap.add_argument("--acoustic-workers", type=int, default=1, help="pipeline workload: s2mel + vocoder stages of different batches in flight at once")
@@ -590,6 +623,33 @@ def main() -> int:
         log(f"[bench] rank {rank}: {len(outs)} pipelined outputs equal the sequential synthesize_batch bit for bit: {equal_seq}")
         assert equal_seq, "a pipelined batch differs from the sequential result"
 
+    # The same pipelined run in the EXACT decode mode (fp32 KV cache: nothing is rounded between the weights and the logits, so the
+    # greedy codes are the oracle's up to fp32 summation order) -- reported beside the headline when the headline stores the cache as bf16.
+    exact_mode = None
+    tts_obj = getattr(step, "tts", None)
+    if (args.workload == "pipeline" and not args.no_exact_mode and tts_obj is not None and tts_obj.gpt.kv_format == "bf16" and not args.no_overlap
+            and not args.longform):
+        k2 = max(2, min(args.steps, 6))
+        tts_obj.gpt.set_kv_format("f32")
+        step(last=True); flush(); torch.cuda.synchronize()
+        barrier()
+        t2 = time.perf_counter()
+        for k in range(k2):
+            step(last=(k == k2 - 1))
+        flush()
+        barrier()
+        e2 = time.perf_counter() - t2
+        if world > 1:
+            tm2 = torch.tensor([e2], device=dev, dtype=torch.float64)
+            dist.all_reduce(tm2, op=dist.ReduceOp.MAX)
+            e2 = float(tm2.item())
+        tts_obj.gpt.set_kv_format("bf16")
+        exact_mode = {"gpt_kv": "f32", "gpt_weights": args.gpt_weights, "value": round(audio_s_per_step_per_gpu * world * k2 / e2, 2), "unit": "audio_s/s",
+                      "steps": k2, "ms_per_step": round(1000 * e2 / k2, 3),
+                      "note": "the same pipelined run with the KV cache stored fp32 (bench.py --gpt-kv f32): the mode whose greedy codes equal the "
+                              "oracle's up to fp32 summation order; its parity figures: cpu_baseline.decode_parity.f32"}
+        log(f"[bench] exact mode (fp32 KV cache): {k2} steps in {e2:.3f}s = {exact_mode['value']} audio-s/s")
+
     roofline = stages = roofline_stages = None
     if rank == 0 and not args.no_roofline:
         # same work again with per-launch HIP events on the launch stream (graph replay is bypassed while profiling)
@@ -665,6 +725,12 @@ def main() -> int:
             "config": cfgd, "audio_s_per_s_per_gpu": round(value / world, 2), "rtf": round(elapsed / audio_total, 6),
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        if exact_mode:
+            if cpu_baseline and "decode_parity" in cpu_baseline and "f32" in cpu_baseline["decode_parity"]:
+                pe = cpu_baseline["decode_parity"]["f32"]
+                exact_mode.update({"greedy_codes_equal_vs_gpu": pe["free_running_codes_equal"], "codes_match_rate": pe["codes_match_rate_teacher_forced"],
+                                   "max_abs_logit_diff": pe["max_abs_logit_diff"], "logit_bound": pe["logit_bound"]})
+            res["exact_mode"] = exact_mode
         if roofline_stages:
             res["roofline_stages"] = roofline_stages
         if stages:

@@ -202,6 +202,15 @@ int idxtts_gpt_embed(idxtts_ctx* ctx, float* out, int rows, const int* text_ids,
 int idxtts_gpt_generate(idxtts_ctx* ctx, const float* inputs_embeds, const int* pad_left, int B, int P, int max_new_tokens,
                         float repetition_penalty, long long* codes, int* n_steps, float* logits_out, void* workspace,
                         size_t workspace_bytes, int use_graph, void* stream);
+/* Parity instrument: the greedy loop above TEACHER-FORCED on forced_codes (device int64 [B][max_new_tokens]) -- at every step the
+ * row's own argmax (after the repetition penalty) is written to `codes`, and forced_codes[b][step] is what continues the sequence
+ * (input_ids of the next step, the penalty set, the finished flag: transformers_generation_utils.py:3252-3264 with next_tokens
+ * replaced).  With logits_out it yields the logits of a GIVEN token sequence, i.e. what a test compares with the reference's logits on
+ * the reference's own codes when two correct implementations may part at a near-tie of the argmax.  Eager launches, no graph.
+ * *n_steps = steps run (stops early only when every forced row has emitted the stop token). */
+int idxtts_gpt_generate_forced(idxtts_ctx* ctx, const float* inputs_embeds, const int* pad_left, int B, int P, int max_new_tokens,
+                               float repetition_penalty, const long long* forced_codes, long long* codes, int* n_steps, float* logits_out,
+                               void* workspace, size_t workspace_bytes, void* stream);
 /* The same generation loop with multinomial sampling instead of argmax (reference default do_sample=True,
  * infer_v2.py:714-722; HF _sample transformers_generation_utils.py:3196-3262 with the warpers of 1036-1044):
  *   mode 1: repetition penalty -> / temperature -> top-k -> top-p -> softmax -> torch.multinomial(probs, 1);

@@ -383,6 +383,17 @@ int idxtts_gpt_generate(idxtts_ctx* ctx, const float* inputs_embeds, const int* 
   API_END
 }
 
+int idxtts_gpt_generate_forced(idxtts_ctx* ctx, const float* inputs_embeds, const int* pad_left, int B, int P, int max_new_tokens,
+                               float repetition_penalty, const long long* forced_codes, long long* codes, int* n_steps, float* logits_out,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  API_BEGIN
+  GPT_MODEL(ctx);
+  IDX_CHECK(forced_codes, "null forced_codes");
+  return m->generate(inputs_embeds, pad_left, B, P, max_new_tokens, repetition_penalty, nullptr, codes, n_steps, logits_out, workspace,
+                     workspace_bytes, 0, static_cast<hipStream_t>(stream), forced_codes);
+  API_END
+}
+
 int idxtts_gpt_generate_sampled(idxtts_ctx* ctx, const float* inputs_embeds, const int* pad_left, int B, int P, int max_new_tokens,
                                 float repetition_penalty, const idxtts_sampling* sampling, long long* codes, int* n_steps,
                                 float* logits_out, void* workspace, size_t workspace_bytes, int use_graph, void* stream) {

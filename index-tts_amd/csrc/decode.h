@@ -43,6 +43,9 @@ struct SampleArgs {
   const DecodeState* st = nullptr;
   int B = 0, V = 0, stop_token = 0;
   float penalty = 1.0f;
+  // teacher forcing (idxtts_gpt_generate_forced): `codes` still records the row's own argmax, but the token fed back (cur_tok, the
+  // repetition-penalty set, the finished flag) is forced[b][step]
+  const long long* forced = nullptr; int forced_ld = 0;
 };
 int sample_greedy_forward(const SampleArgs& a, hipStream_t stream);
 

@@ -479,7 +479,9 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs p)
     for (int w = 1; w < 16; ++w)
       if (rv[w] > best || (rv[w] == best && ri[w] < bidx)) { best = rv[w]; bidx = ri[w]; }
     int tok = p.finished[b] ? p.stop_token : bidx;      // finished rows emit pad (= eos = stop token)
-    p.codes[(size_t)b * p.codes_ld + p.st->step] = tok;
+    const int step = p.st->step;
+    p.codes[(size_t)b * p.codes_ld + step] = tok;
+    if (p.forced) tok = (int)p.forced[(size_t)b * p.forced_ld + step];      // teacher forcing: the given token continues the sequence
     p.seen[(size_t)b * V + tok] = 1;
     if (tok == p.stop_token) p.finished[b] = 1;
     p.cur_tok[b] = tok;

@@ -82,7 +82,7 @@ struct GPTModel : ModelBase {
   // (the sampling mode of the generation in flight is thread-local state in gpt.hip: generate() is re-entrant across host threads,
   //  each call with its own workspace and stream)
   int generate(const float* inputs_embeds, const int* pad_left_host, int B, int P, int max_new, float penalty, const idxtts_sampling* sampling, long long* codes,
-               int* n_steps_out, float* logits_out, void* ws, size_t ws_bytes, int use_graph, hipStream_t st);
+               int* n_steps_out, float* logits_out, void* ws, size_t ws_bytes, int use_graph, hipStream_t st, const long long* forced = nullptr);
   // Beam search / beam-sample (HF _beam_search; the reference's default decoding mode, infer_v2.py:714-722): B utterances x
   // num_beams rows through the same decode step, selection / hypotheses / re-indexing on the device (beam.hip).
   size_t beam_workspace_bytes(int B, int nb, int S, int max_new) const;

@@ -299,7 +299,9 @@ int GPTModel::layer_full(int li, const Buffers& w, int B, int S, const int* ksta
 // sampling mode of the generation this host thread is running (mode 0 = greedy)
 static thread_local idxtts_sampling samp{0, 1.0f, 0, 1.0f, nullptr, 0};
 thread_local const BeamState* tl_beam = nullptr;
-static thread_local int tl_prof_pos = 0;      // keys the eager decode step in flight reads (0 while a captured graph replays)
+static thread_local int tl_prof_pos = 0;
+static thread_local const long long* tl_forced = nullptr;      // teacher-forced generation in flight: [B][max_new] tokens fed back instead of the argmax
+static thread_local int tl_forced_ld = 0;      // keys the eager decode step in flight reads (0 while a captured graph replays)
 
 // head on B rows: ln_f -> final_norm (one rows_norm launch, output as fragment images) -> mel_head -> greedy sampler
 int GPTModel::head_and_sample(const Buffers& w, int B, const float* x, int ldx, bool x_frag, float penalty, long long* codes,
@@ -317,6 +319,7 @@ int GPTModel::head_and_sample(const Buffers& w, int B, const float* x, int ldx, 
   s.part = w.logits; s.parts = 1; s.part_rows = B; s.bias = nullptr; s.logits_out = logits_out;
   s.seen = w.seen; s.finished = w.finished; s.codes = codes; s.codes_ld = codes_ld; s.cur_tok = w.cur_tok;
   s.st = w.state; s.B = B; s.V = V; s.stop_token = cfg.stop_mel_token; s.penalty = penalty;
+  s.forced = tl_forced; s.forced_ld = tl_forced_ld;
   if (samp.mode != 0) {
     SampleWarpArgs sw;
     sw.base = s; sw.mode = samp.mode; sw.temperature = samp.temperature; sw.top_k = samp.top_k; sw.top_p = samp.top_p;
@@ -371,8 +374,13 @@ int GPTModel::decode_step(const Buffers& w, int B, float penalty, long long* cod
 
 int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int B, int P, int max_new, float penalty,
                        const idxtts_sampling* sampling, long long* codes, int* n_steps_out, float* logits_out, void* ws, size_t ws_bytes, int use_graph,
-                       hipStream_t user_stream) {
+                       hipStream_t user_stream, const long long* forced) {
   IDX_CHECK(inputs_embeds && codes && n_steps_out, "null pointer");
+  struct ForcedScope {      // the forced tokens apply to this call only, whatever path it returns on
+    ForcedScope(const long long* f, int ld) { tl_forced = f; tl_forced_ld = ld; }
+    ~ForcedScope() { tl_forced = nullptr; tl_forced_ld = 0; }
+  } forced_scope(forced, max_new);
+  IDX_CHECK(!forced || !(sampling && sampling->mode != 0), "teacher forcing is a greedy-mode instrument");
   // The legacy default stream cannot be captured into a graph: run on a private stream, ordered after
   // everything already queued by the caller (the call ends with a host sync anyway: n_steps is a host value).
   hipStream_t st = user_stream;
@@ -448,7 +456,7 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
     ~SlotLease() { if (m && idx >= 0) { std::lock_guard<std::mutex> l(m->graph_mu); m->graph_cache[idx].in_use = false; } }
   } lease;
   hipGraphExec_t exec = nullptr;
-  const bool graph_ok = use_graph && !logits_out && !prof_enabled();
+  const bool graph_ok = use_graph && !logits_out && !forced && !prof_enabled();
   const bool cacheable = samp.mode == 0 && !tl_beam;      // greedy: nothing call-specific is baked into the launches
   int n_first = 1;
   if (graph_ok && max_new > 2) {
@@ -530,7 +538,7 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
     if (first < 0) every_row_stops = false;
     else worst = std::max(worst, first + 1);
   }
-  if (every_row_stops) n_steps = worst;
+  if (every_row_stops && !forced) n_steps = worst;      // forced: every step that ran is reported (codes = the rows' own choices)
   *n_steps_out = n_steps;
   return 0;
 }

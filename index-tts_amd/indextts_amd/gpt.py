@@ -212,7 +212,7 @@ class UnifiedVoice:
                  tts_embeddings: Optional[torch.Tensor] = None, tts_mel_embedding=None, tts_text_pos_embedding=None,
                  repetition_penalty: float = 10.0, return_logits: bool = False, use_graph: bool = True,
                  do_sample: bool = False, sampler: str = "hf", exp_noise: Optional[torch.Tensor] = None,
-                 generator: Optional[torch.Generator] = None) -> torch.Tensor:
+                 generator: Optional[torch.Generator] = None, forced_codes: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The accel-engine plugin contract (accel_engine.py:378-645): returns LongTensor [B, P+1+generated]
         (prompt ids followed by the generated codes, padded with the stop token).
 
@@ -221,7 +221,9 @@ class UnifiedVoice:
         transformers_generation_utils.py:1036-1044, 3222-3250), sampler="accel" = the accel engine's own Sampler
         (softmax(logits / T) / Exp(1) noise, argmax; accel_engine.py:648-659).  torch.multinomial(probs, 1) is
         argmax(probs / q) with q ~ Exp(1): `exp_noise` [max_new_tokens, B, V] supplies the draws, or `generator` draws them on the
-        CPU with one exponential_() per step, the order HF consumes them; with neither the kernels generate them (see _noise)."""
+        CPU with one exponential_() per step, the order HF consumes them; with neither the kernels generate them (see _noise).
+        forced_codes [B, max_new_tokens] (greedy only; a parity instrument, `idxtts_gpt_generate_forced`): the sequence is continued with
+        these tokens while the returned codes are each step's own argmax -- with return_logits, the logits of a GIVEN token sequence."""
         if tts_embeddings is None:
             raise ValueError("tts_embeddings ([pad][cond][text] prompt embeddings) is required")
         if stop_tokens is not None and list(stop_tokens) != [self.cfg.stop_mel_token]:
@@ -239,6 +241,8 @@ class UnifiedVoice:
         logits = torch.zeros(max_new_tokens, B, V, device=self.device) if return_logits else None
         ws = self._workspace(B, P + 1, max_new_tokens)
         n = ctypes.c_int(0)
+        if do_sample and forced_codes is not None:
+            raise ValueError("forced_codes is a greedy-mode instrument")
         if do_sample:
             if sampler not in ("hf", "accel"):
                 raise ValueError("sampler must be 'hf' or 'accel'")
@@ -251,6 +255,13 @@ class UnifiedVoice:
                 self._h, _lib.ptr(emb), pad_left.ctypes.data_as(c_void_p), B, P, max_new_tokens, float(repetition_penalty),
                 ctypes.byref(sc), _lib.ptr(codes), ctypes.byref(n), _lib.ptr(logits), _lib.ptr(ws), ws.numel(), int(use_graph),
                 _lib.current_stream()))
+        elif forced_codes is not None:
+            fc = forced_codes.to(self.device, torch.long).contiguous()
+            if tuple(fc.shape) != (B, max_new_tokens):
+                raise ValueError(f"forced_codes must be {(B, max_new_tokens)}")
+            _lib.check(_lib.load().idxtts_gpt_generate_forced(
+                self._h, _lib.ptr(emb), pad_left.ctypes.data_as(c_void_p), B, P, max_new_tokens, float(repetition_penalty), _lib.ptr(fc),
+                _lib.ptr(codes), ctypes.byref(n), _lib.ptr(logits), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
         else:
             _lib.check(_lib.load().idxtts_gpt_generate(
                 self._h, _lib.ptr(emb), pad_left.ctypes.data_as(c_void_p), B, P, max_new_tokens, float(repetition_penalty),
@@ -340,6 +351,7 @@ class UnifiedVoice:
         samp = {"do_sample": do_sample, "top_p": hf_generate_kwargs.pop("top_p", 1.0), "top_k": hf_generate_kwargs.pop("top_k", 50),
                 "temperature": hf_generate_kwargs.pop("temperature", 1.0), "exp_noise": hf_generate_kwargs.pop("exp_noise", None),
                 "generator": hf_generate_kwargs.pop("generator", None)}
+        forced_codes = hf_generate_kwargs.pop("forced_codes", None)
         sampler = hf_generate_kwargs.pop("sampler", "hf")
         length_penalty = float(hf_generate_kwargs.pop("length_penalty", 1.0))
         early_stopping = hf_generate_kwargs.pop("early_stopping", False)
@@ -361,7 +373,7 @@ class UnifiedVoice:
             return out[:, trunc_index:], speech_conditioning_latent
         out = self.generate(input_ids, max_new_tokens=max_new, stop_tokens=[self.cfg.stop_mel_token],
                             attention_mask=attention_mask, tts_embeddings=inputs_embeds, repetition_penalty=penalty,
-                            return_logits=return_logits, sampler=sampler, use_graph=use_graph, **samp)
+                            return_logits=return_logits, sampler=sampler, use_graph=use_graph, forced_codes=forced_codes, **samp)
         if return_logits:
             return out[0][:, trunc_index:], speech_conditioning_latent, out[1]
         return out[:, trunc_index:], speech_conditioning_latent

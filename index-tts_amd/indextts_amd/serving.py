@@ -116,25 +116,31 @@ class BatchPipeline:
             for r in group:
                 sg.wait_event(r.ready)
             text = group[0].text if len(group) == 1 else torch.cat([torch.as_tensor(r.text).cpu() for r in group])      # equal widths
+            subs = []
             with torch.cuda.stream(sg):
                 st = self.tts.gpt_stage(text, group[0].cond, max_mel_tokens=group[0].max_mel_tokens,
                                         repetition_penalty=group[0].repetition_penalty, sampling=group[0].sampling)
+                # every request's rows as its own state, cut on the LANE's stream: the slicing copies below are launches like any
+                # other, and the acoustic worker reads their results on a stream of its own -- they must be inside what the
+                # host-side wait below covers (and allocated from this stream's pool)
+                a = 0
+                for r in group:
+                    b = a + int(r.text.shape[0])
+                    n = max(st["code_lens"][a:b])
+                    subs.append({"cond": st["cond"], "B": b - a, "codes": st["codes"][a:b, :n].contiguous(), "code_lens": st["code_lens"][a:b],
+                                 "code_lens_t": st["code_lens_t"][a:b].clone(), "latent": st["latent"][a:b, :n].contiguous(),
+                                 "times": dict(st["times"])})
+                    a = b
             # The lane waits for its own stream on the host (the decode has synchronised already, what is left is the latent
-            # pass): a device-side event wait from the acoustic stream is not an option -- HIP refuses to wait on an event whose
-            # stream is capturing, and this lane may be capturing the next batch's decode step by then.
+            # pass and the slices): a device-side event wait from the acoustic stream is not an option -- HIP refuses to wait on an
+            # event whose stream is capturing, and this lane may be capturing the next batch's decode step by then.
             sg.synchronize()
             if self.trace is not None:
                 self.trace.append(("decode", t0, time.perf_counter(), int(text.shape[0])))
-            a = 0
-            for r in group:                      # every request's rows go to its own acoustic job
-                b = a + int(r.text.shape[0])
-                n = max(st["code_lens"][a:b])
-                sub = {"cond": st["cond"], "B": b - a, "codes": st["codes"][a:b, :n].contiguous(), "code_lens": st["code_lens"][a:b],
-                       "code_lens_t": st["code_lens_t"][a:b].clone(), "latent": st["latent"][a:b, :n].contiguous(), "times": dict(st["times"])}
+            for r, sub in zip(group, subs):      # every request's rows go to its own acoustic job
                 with self._qlock:
                     self._aq.append((r, sub))
                 self._acoustic.submit(self._acoustic_drain)      # one drain per request: a drain that finds nothing (merged away) returns
-                a = b
         except BaseException as e:                  # noqa: BLE001 -- handed to the callers through their futures
             for r in group:
                 if not r.done.done():

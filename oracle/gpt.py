@@ -309,12 +309,21 @@ def generate_beam(w, cfg, conds: torch.Tensor, text_inputs: torch.Tensor, max_ne
         n_keep = 2 * nb
         if do_sample:
             probs = F.softmax(scores, dim=-1)
-            cand = torch.topk(probs / exp_noise[step].float(), n_keep, dim=-1)[1]       # == torch.multinomial(probs, n_keep)
+            key = probs / exp_noise[step].float()
+            cand = torch.topk(key, n_keep, dim=-1)[1]       # == torch.multinomial(probs, n_keep)
             cand_scores = torch.gather(scores, -1, cand)
             cand_scores, order = torch.sort(cand_scores, descending=True, dim=1)
             cand = torch.gather(cand, -1, order)
         else:
+            key = scores
             cand_scores, cand = torch.topk(scores, n_keep, dim=1, largest=True, sorted=True)
+        if return_trace:
+            # how close this step's decisions are: the smallest gap between neighbours among the best n_keep + 1 selection keys (who is
+            # drawn), relative for the sampling key probs / q, and among the drawn candidates' scores (their order = the beams' order)
+            kt = torch.topk(key, n_keep + 1, dim=-1)[0]
+            gsel = (kt[:, :-1] - kt[:, 1:]) / (kt[:, :-1].abs().clamp_min(1e-30) if do_sample else 1.0)
+            gord = cand_scores[:, :-1] - cand_scores[:, 1:]
+            step_gap = torch.minimum(gsel.min(dim=1)[0], gord.min(dim=1)[0])
         cand_beam = torch.div(cand, V, rounding_mode="floor")
         cand_tok = cand % V
         # ---- BeamSearchScorer.process ----
@@ -343,7 +352,7 @@ def generate_beam(w, cfg, conds: torch.Tensor, text_inputs: torch.Tensor, max_ne
         beam_scores = nxt_scores.view(-1)
         beam_idx = nxt_idx.view(-1)
         if return_trace:
-            trace.append((beam_idx.clone(), nxt_tok.view(-1).clone(), beam_scores.clone()))
+            trace.append((beam_idx.clone(), nxt_tok.view(-1).clone(), beam_scores.clone(), step_gap.clone()))
         input_ids = torch.cat([input_ids[beam_idx], nxt_tok.view(-1, 1)], dim=-1)
         past = [(k.index_select(0, beam_idx), v.index_select(0, beam_idx)) for k, v in past]
         attention_mask = torch.cat([attention_mask, torch.ones(B * nb, 1, dtype=torch.long)], dim=1)

@@ -211,16 +211,22 @@ def test_beam_search_at_full_size_16_utterances_vs_oracle(device, full):
     torch.set_num_threads(16)
     for do_sample in (False, True):
         with torch.no_grad():
-            want = og.generate_beam(tw, g, conds, text, NEW, noise, num_beams=NB, do_sample=do_sample)
+            want, trace = og.generate_beam(tw, g, conds, text, NEW, noise, num_beams=NB, do_sample=do_sample, return_trace=True)
         codes, _ = uv.inference_speech(c.spk_cond_latent.expand(B, -1, -1), text, emo_vec=c.emo_vec.expand(B, -1), max_generate_length=NEW,
                                        do_sample=do_sample, num_beams=NB, top_p=0.8, top_k=30, temperature=0.8, repetition_penalty=10.0,
                                        length_penalty=0.0, exp_noise=noise)
         got = codes.cpu().numpy()
         assert got.shape == tuple(want.shape), (got.shape, tuple(want.shape))
-        mism = int((got != want.numpy()).any(axis=1).sum())
-        # exact-fp32 kernels vs torch CPU: summation order differs, so a near-tie between candidates may flip a row once in a while;
-        # at most one of the 16 utterances may differ, and every row must agree up to its first differing token's neighbourhood
-        assert mism <= 1, f"{mism} of {B} utterances differ (do_sample={do_sample})"
+        rows = np.nonzero((got != want.numpy()).any(axis=1))[0]
+        # exact-fp32 kernels vs torch CPU: summation order differs (scores agree to ~1e-4), so a near-tie between two candidates may fall
+        # the other way once in a while.  At most one of the 16 utterances may differ, and only where the ORACLE's own decision was that
+        # close: up to the first differing token, some step of that utterance must have had two neighbouring selection keys / candidate
+        # scores within 2e-3 (sampling key: relative) -- otherwise the difference is a bug, not a tie.
+        assert len(rows) <= 1, f"{len(rows)} of {B} utterances differ (do_sample={do_sample})"
+        for b in rows:
+            t = int(np.nonzero(got[b] != want.numpy()[b])[0][0])
+            gaps = [float(tr[3][b]) for tr in trace[: t + 1]]
+            assert min(gaps) <= 2e-3, f"utterance {b} differs from step {t} on, but the oracle's closest decision up to there had a gap of {min(gaps):.3e}"
 
 
 def test_bf16_weights_and_kv_cache_16_utterances_vs_oracle(device, full):
@@ -254,3 +260,42 @@ def test_bf16_weights_and_kv_cache_16_utterances_vs_oracle(device, full):
             assert got.shape == tuple(ref.shape) and np.array_equal(got, ref.numpy()), narrow
     finally:
         _lib.set_decode_geometry(False)
+
+
+def _parity_setup(full, device, kv_format):
+    from indextts_amd.gpt import UnifiedVoice
+    cfg, wg, ws, wv = full
+    g = cfg.gpt
+    uv = UnifiedVoice(wg, g, device=device, weight_format="bf16", keep_effective=True, kv_format=kv_format)
+    tw = {k: torch.from_numpy(v) for k, v in uv.effective_state_dict.items()}
+    c = _cond(cfg)
+    B, L = 4, 32
+    text = torch.from_numpy(synth.integers("bench/text/rank0", (16, 128), 2, g.number_text_tokens))[:B, :L].clone()      # bench.py's CPU-leg prefixes
+    return uv, tw, g, c.spk_cond_latent.expand(B, -1, -1).contiguous(), c.emo_vec.expand(B, -1).contiguous(), text
+
+
+# What the two storage modes of the decode may add to a logit against the fp32 CPU oracle running the same (rounded) model, full size
+# (logit std ~ 1; measured on MI355X: tests print the figure).  bench.py reports the same quantities on its CPU-leg utterances.
+LOGIT_BOUND = {"f32": 4e-4, "bf16": 4e-3}
+
+
+@pytest.mark.parametrize("kv_format", ["bf16", "f32"])
+def test_decode_teacher_forced_logit_bound_and_every_code_flip_is_a_near_tie(device, full, kv_format):
+    """The bench's decode mode (bf16 weight streams; bf16 or fp32 KV cache), full-size GPT, 4 utterances x 96 steps TEACHER-FORCED on the
+    oracle's codes (oracle/parity.py): every logit within LOGIT_BOUND of the oracle's, every step whose argmax differs from the oracle's
+    token is a near-tie of the ORACLE (margin below twice the bound), and the free-running decode leaves the oracle's sequence exactly
+    at the first such step of an utterance -- nowhere else."""
+    from oracle import parity
+    uv, tw, g, lat, emo, text = _parity_setup(full, device, kv_format)
+    torch.set_num_threads(16)
+    r = parity.decode_parity(uv, tw, g, lat, emo, text, 96)
+    bound = LOGIT_BOUND[kv_format]
+    print(f"[parity {kv_format}] max|dlogit| {r['max_abs_logit_diff']:.3e} (mean {r['mean_abs_logit_diff']:.3e}, logit std {r['logit_std']:.2f}), "
+          f"teacher-forced match rate {r['codes_match_rate_teacher_forced']:.4f}, mismatches {r['mismatching_steps']}, "
+          f"oracle top-2 margin median {r['oracle_top2_margin_median']:.3e} min {r['oracle_top2_margin_min']:.3e}, free-running first differences {r['first_difference_step_free_running']}")
+    assert r["steps"] == 96 and r["utterances"] == 4
+    assert r["max_abs_logit_diff"] <= bound, r["max_abs_logit_diff"]
+    for t in r["mismatching_steps"]:
+        assert 0.0 <= t["oracle_margin_to_hip_token"] <= 2 * bound, t
+    assert r["codes_match_rate_teacher_forced"] >= 0.97
+    assert r["first_difference_step_free_running"] == r["first_mismatch_step_teacher_forced"]
