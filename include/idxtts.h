@@ -126,6 +126,15 @@ int idxtts_get_gemm_mode(void);
  * waves, so results differ in the last bits: choose once per process, before generating (cached decode graphs carry the choice). */
 int idxtts_set_decode_geometry(int narrow);
 int idxtts_get_decode_geometry(void);
+/* From how many decode rows on (compact weight streams) the decode step runs on the plane GEMV (csrc/gemv_pl.hip: activations split
+ * into three bf16 planes inside the kernel, bf16 MFMA with exact products, K split over waves and workgroups, one weight stream
+ * for up to 64 rows -- the accel engine's one-graph-for-all-rows batching, accel/accel_engine.py:221-310) instead of the fp32-MFMA
+ * GEMV.  Default 17: two or more 16-row tiles (merged requests, 16 utterances x 3 beams: 7 % faster at 48 rows); at <= 16 rows the
+ * fp32-MFMA GEMV's single-round-trip launches win by 8 %.  5..64 selects a threshold, 65 turns the plane path off, 0 restores the
+ * default.  Rows of 17..64-row decodes do not depend on the batch they are in; the two kernel families differ in summation order
+ * (last bits), so choose once per process, before generating (cached decode graphs carry the choice). */
+int idxtts_set_decode_plane_rows(int min_rows);
+int idxtts_get_decode_plane_rows(void);
 /* The CFM solver (idxtts_s2mel_cfm) can evaluate the conditional and the null half of its stacked batch (flow_matching.py:91-103,
  * one DiT.forward on 2B rows there) as two chains of launches on two streams, the null half a few kernels behind: same kernels
  * on the same rows, bit-identical results, 9 % less time for a solver that has the device to itself (one half's HBM-bound

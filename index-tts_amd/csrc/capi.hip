@@ -657,6 +657,16 @@ int idxtts_set_decode_geometry(int narrow) {
 
 int idxtts_get_decode_geometry(void) { return get_decode_geometry(); }
 
+int idxtts_set_decode_plane_rows(int min_rows) {
+  API_BEGIN
+  IDX_CHECK(min_rows == 0 || (min_rows >= 5 && min_rows <= 65), "0 (default), 5..64 or 65 (off)");
+  set_decode_plane_rows(min_rows);
+  return 0;
+  API_END
+}
+
+int idxtts_get_decode_plane_rows(void) { return get_decode_plane_rows(); }
+
 int idxtts_s2mel_set_overlap(int on) {
   set_s2mel_overlap(on);
   return 0;

@@ -7,7 +7,7 @@ struct DecodeState {   // device-resident per-generation scalars (replay-friendl
   int pos;       // KV index of the token being processed (= keys already in the cache)
   int mel_pos;   // row of mel_pos_embedding for that token (reference quirk: 0, 2, 3, 4, ... model_v2.py:175-177)
   int step;      // column of `codes` the sampler writes
-  int pad;
+  unsigned arrive;   // workgroups of the fused sample + embed + advance launch that have finished (0 between launches)
 };
 
 struct DecodeAttnArgs {
@@ -16,7 +16,8 @@ struct DecodeAttnArgs {
   // this layer's cache.  kv16 = 0: fp32, K [B][H][16][Smax][4], V [B][H][Smax][64].  kv16 = 1: bf16 (rounded to nearest even when a
   // key / value is produced, the new token's own included), K [B][H][8][Smax][8], V [B][H][Smax][64]: 16-byte granules either way
   void* kcache = nullptr; void* vcache = nullptr; int kv16 = 0;
-  float* out = nullptr;                                                 // [B][d] as A-fragment images (frag_index)
+  float* out = nullptr;                                                 // [B][d] as A-fragment images (frag_index), or
+  float* out_row = nullptr;                                             // as fp32 rows [B][d] (the plane GEMV's input, gemv_pl.h)
   const int* kstart = nullptr;                                          // [B] first valid key (left pad), or null
   const DecodeState* st = nullptr;
   int B = 0, H = 0, Smax = 0, d = 0;
@@ -46,6 +47,15 @@ struct SampleArgs {
   // teacher forcing (idxtts_gpt_generate_forced): `codes` still records the row's own argmax, but the token fed back (cur_tok, the
   // repetition-penalty set, the finished flag) is forced[b][step]
   const long long* forced = nullptr; int forced_ld = 0;
+  // Fused tail of a greedy step on the plane-GEMV path (embed.x_row != null): the workgroup that picked row b's token also writes the NEXT
+  // step's input x[b] = mel_emb[token] + mel_pos[st->mel_pos + 1] (model_v2.py:173-177) -- as the fp32 residual row
+  // and the per-16-column row statistics of the first folded LayerNorm -- and the last workgroup to arrive advances the
+  // step scalars (DecodeState::arrive counts them): sample + embed + advance in ONE launch.
+  struct Embed {
+    float* x_row = nullptr; float* x_stats = nullptr;
+    const float* mel_emb = nullptr; const float* mel_pos = nullptr; int d = 0;
+    DecodeState* st_rw = nullptr;
+  } embed;
 };
 int sample_greedy_forward(const SampleArgs& a, hipStream_t stream);
 
@@ -96,5 +106,8 @@ struct GatherArgs {
 int gather_sum_rows(const GatherArgs& a, int rows, hipStream_t stream);
 int embed_step(float* x, int B, int d, const float* mel_emb, const float* mel_pos, const int* cur_tok, const DecodeState* st,
                hipStream_t stream);
+// the same for the plane-GEMV path: x as fp32 rows [B][d] + the row statistics per 16 columns
+int embed_step_pl(float* x_row, float* x_stats, int B, int d, const float* mel_emb, const float* mel_pos, const int* cur_tok,
+                  const DecodeState* st, hipStream_t stream);
 
 }  // namespace idxtts

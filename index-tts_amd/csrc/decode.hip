@@ -39,8 +39,12 @@ __device__ __forceinline__ float wave_add(float v) {
 __device__ __forceinline__ void decode_attn_finish(const DecodeAttnArgs& p, const int b, const int h, const int z, const int NS, const int tid,
                                                    const float o, const float mx, const float l) {
   const int d = p.d;
+  auto put = [&](float val) {      // input of the c_proj GEMV: an A-fragment image (gemv_fx.hip) or a plain fp32 row (gemv_pl.hip)
+    if (p.out_row) p.out_row[(size_t)b * d + h * 64 + tid] = val;
+    else p.out[frag_index(b, h * 64 + tid, d >> 4)] = val;
+  };
   if (NS == 1) {
-    if (tid < 64) p.out[frag_index(b, h * 64 + tid, d >> 4)] = l > 0.f ? o / l : 0.f;     // A-fragment image for the c_proj GEMV
+    if (tid < 64) put(l > 0.f ? o / l : 0.f);
     return;
   }
   // ---- key split: leave (o, max, sum) of this piece; the last piece to arrive merges all of them in piece order ----
@@ -77,7 +81,7 @@ __device__ __forceinline__ void decode_attn_finish(const DecodeAttnArgs& p, cons
     O += wgt * oi[i];
     L += wgt * li[i];
   }
-  p.out[frag_index(b, h * 64 + tid, d >> 4)] = L > 0.f ? O / L : 0.f;
+  put(L > 0.f ? O / L : 0.f);
 }
 
 // NT threads per workgroup: NT / 16 key groups in the P.V phase, NT keys per pass of the score phase.  512 threads at <= 128
@@ -411,7 +415,7 @@ int decode_attn_nsplit(int B, int H) {
 }
 
 int decode_attn_forward(const DecodeAttnArgs& a, hipStream_t stream) {
-  IDX_CHECK(a.qkv_part && a.kcache && a.vcache && a.out && a.st, "null pointer");
+  IDX_CHECK(a.qkv_part && a.kcache && a.vcache && (a.out || a.out_row) && a.st, "null pointer");
   IDX_CHECK(a.d == a.H * 64, "head_dim must be 64");
   constexpr int nt = 512;      // 512 threads measured 4 % faster than 256 (profiles/README.md)
   const size_t lds = (size_t)(256 + (nt / (a.kv16 ? 8 : 16)) * 64 + a.Smax) * sizeof(float);
@@ -433,9 +437,34 @@ int decode_attn_forward(const DecodeAttnArgs& a, hipStream_t stream) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// x[b] = mel_emb[tok] + mel_pos[mp] for the plane-GEMV decode step: fp32 row + (mean, M2) per 16 columns
+template <int NT>
+__device__ __forceinline__ void embed_row_pl(float* x_row, float* x_stats, const int b, const int B, const int d, const float* mel_emb,
+                                             const float* mel_pos, const int tok, const int mp, const int tid) {
+  const int R = ((B + 15) >> 4) * 16;
+  for (int e0 = 0; e0 < d; e0 += NT) {      // d % 16 == 0: a 16-column tile never straddles the loop's edge or a wave
+    const int e = e0 + tid;
+    const bool on = e < d;
+    const float v = on ? mel_emb[(size_t)tok * d + e] + mel_pos[(size_t)mp * d + e] : 0.f;
+    float s = v;
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m);
+    const float mean = s * 0.0625f;
+    float q = (v - mean) * (v - mean);
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) q += __shfl_xor(q, m);
+    if (on) {
+      x_row[(size_t)b * d + e] = v;
+      if ((e & 15) == 0) *reinterpret_cast<float2*>(&x_stats[((size_t)(e >> 4) * R + b) * 2]) = make_float2(mean, q);
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs p) {
   __shared__ float rv[16];
   __shared__ int ri[16];
+  __shared__ int s_tok;
+  const int mp_next = p.embed.x_row ? p.st->mel_pos + 1 : 0;      // read before anybody can advance the state
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int V = p.V;
   float best = -INFINITY;
@@ -485,6 +514,19 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs p)
     p.seen[(size_t)b * V + tok] = 1;
     if (tok == p.stop_token) p.finished[b] = 1;
     p.cur_tok[b] = tok;
+    s_tok = tok;
+  }
+  if (!p.embed.x_row) return;
+  __syncthreads();
+  embed_row_pl<1024>(p.embed.x_row, p.embed.x_stats, b, p.B, p.embed.d, p.embed.mel_emb, p.embed.mel_pos, s_tok, mp_next, tid);
+  __syncthreads();      // every read of the step scalars by this workgroup is behind us
+  if (tid == 0) {
+    DecodeState* st = p.embed.st_rw;
+    const unsigned old = __hip_atomic_fetch_add(&st->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == gridDim.x - 1u) {      // everybody has read pos / mel_pos / step: advance them for the next launch
+      __hip_atomic_store(&st->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      st->pos += 1; st->mel_pos += 1; st->step += 1;
+    }
   }
 }
 
@@ -750,6 +792,21 @@ __global__ __launch_bounds__(256) void embed_step_kernel(float* x, int d, const 
   const int b = blockIdx.x;
   const int tok = cur_tok[b], mp = st->mel_pos;
   for (int e = threadIdx.x; e < d; e += 256) x[frag_index(b, e, d >> 4)] = mel_emb[(size_t)tok * d + e] + mel_pos[(size_t)mp * d + e];
+}
+
+__global__ __launch_bounds__(256) void embed_step_pl_kernel(float* x_row, float* x_stats, int B, int d, const float* mel_emb,
+                                                            const float* mel_pos, const int* cur_tok, const DecodeState* st) {
+  embed_row_pl<256>(x_row, x_stats, blockIdx.x, B, d, mel_emb, mel_pos, cur_tok[blockIdx.x], st->mel_pos, threadIdx.x);
+}
+
+int embed_step_pl(float* x_row, float* x_stats, int B, int d, const float* mel_emb, const float* mel_pos, const int* cur_tok,
+                  const DecodeState* st, hipStream_t stream) {
+  IDX_CHECK(d % 16 == 0, "row statistics per 16 columns need d % 16 == 0");
+  static const int cat = prof_register("embed_step_kernel");
+  ProfScope prof(cat, stream, 0.0, 12.0 * B * (double)d);
+  hipLaunchKernelGGL(embed_step_pl_kernel, dim3(B), dim3(256), 0, stream, x_row, x_stats, B, d, mel_emb, mel_pos, cur_tok, st);
+  IDX_LAUNCH_CHECK();
+  return 0;
 }
 
 int embed_step(float* x, int B, int d, const float* mel_emb, const float* mel_pos, const int* cur_tok, const DecodeState* st,

@@ -10,6 +10,7 @@
 #include "decode.h"
 #include "gemm.h"
 #include "gemv16.h"
+#include "gemv_pl.h"
 #include "norm.h"
 #include "prof.h"
 
@@ -19,6 +20,7 @@ struct GPTLayer {
   const float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
   LinearWeights attn_l, proj_l, fc_l, fc2_l;     // MFMA-32x32 packed (prefill / latent pass)
   Gemv16Weights attn_g, proj_g, fc_g, fc2_g;     // stream-order packed (decode); attn_g / fc_g carry diag(ln_g) folded in
+  Gemv32Weights attn_p, proj_p, fc_p, fc2_p;     // compact formats only: the bf16-MFMA order of the plane GEMV (gemv_pl.h), 5..64 rows
   const float *attn_u = nullptr, *attn_c = nullptr;   // folded LayerNorm 1: colsum(diag(g) W), b . W + bias
   const float *fc_u = nullptr, *fc_c = nullptr;       // folded LayerNorm 2
 };
@@ -28,6 +30,7 @@ struct GPTModel : ModelBase {
   std::vector<GPTLayer> layers;
   const float *lnf_g = nullptr, *lnf_b = nullptr, *fn_g = nullptr, *fn_b = nullptr;
   Gemv16Weights head_g;
+  Gemv32Weights head_p;
   const float* head_b = nullptr;
   const float *mel_emb = nullptr, *text_emb = nullptr, *mel_pos = nullptr, *text_pos = nullptr;
   int weight_fmt = WFMT_F32;      // storage format of the decode weight streams (quantize_weights)
@@ -46,6 +49,9 @@ struct GPTModel : ModelBase {
     float *x, *h, *qkv, *att, *ff;            // [B*S][..] prefill / latent activations
     char *kcache, *vcache; int Smax;          // [L][B][H] x (Smax x 64 elements) each; fp32 or bf16 elements (kv_fmt, decode.h)
     float *xd, *hd, *attd, *ffd;              // decode residual / final-normed / attention output / mlp hidden: A-fragment images
+    // plane-GEMV decode step (gemv_pl.h; compact weight streams, more than 4 rows): every activation a plain fp32 row-major matrix,
+    // per-16-column row statistics for the folded LayerNorms, K-part partial sums and arrival counters
+    float *xrow, *hrow, *attrow, *ffrow, *stats, *pl_slab; unsigned* pl_cnt;
     float *qkvd, *logits, *slab;              // [B][3d], [B][V] row-major; [<=8][B][d] K-split partial sums of mlp.c_proj
     size_t frag_off, frag_bytes;              // the fragment-image region (zeroed once per generate: padding rows stay 0)
     unsigned char* seen; int *finished, *cur_tok, *kstart;
@@ -79,6 +85,9 @@ struct GPTModel : ModelBase {
   int head_and_sample(const Buffers& w, int B, const float* x, int ldx, bool x_frag, float penalty, long long* codes, int codes_ld,
                       float* logits_out, hipStream_t st);
   int decode_step(const Buffers& w, int B, float penalty, long long* codes, int codes_ld, float* logits_base, hipStream_t st);
+  int decode_step_pl(const Buffers& w, int B, float penalty, long long* codes, int codes_ld, float* logits_base, hipStream_t st);
+  bool use_pl(int B) const;        // this many decode rows run on the plane GEMV
+  bool fused_tail(int B) const;    // ... and the generation in flight is greedy: sample + embed + advance are one launch
   // (the sampling mode of the generation in flight is thread-local state in gpt.hip: generate() is re-entrant across host threads,
   //  each call with its own workspace and stream)
   int generate(const float* inputs_embeds, const int* pad_left_host, int B, int P, int max_new, float penalty, const idxtts_sampling* sampling, long long* codes,

@@ -77,8 +77,26 @@ static int upload_stream(DeviceArena& arena, const std::vector<float>& buf, int 
   return 0;
 }
 
+// the same matrix in the plane GEMV's order (compact formats only; gemv_pl.h)
+static int upload_stream32(DeviceArena& arena, const float* w, int N, int K, bool kn, int fmt, Gemv32Weights* gp) {
+  gp->N = N; gp->K = K; gp->fmt = fmt;
+  if (fmt == WFMT_F32) return 0;
+  std::vector<unsigned char> cbuf(gemv32_packed_elems(N, K) * wfmt_bytes(fmt));
+  std::vector<float> scale(N, 1.0f);
+  if (pack_gemv32(cbuf.data(), w, N, K, kn, fmt, scale.data())) IDX_FAIL("decode weights are not representable in the compact format (quantize_weights not applied?)");
+  void* d = nullptr;
+  if (arena.upload_bytes(cbuf.data(), cbuf.size(), &d)) return 1;
+  gp->wp = d;
+  if (fmt == WFMT_FP8) {
+    float* ds = nullptr;
+    if (arena.upload(scale.data(), scale.size(), &ds)) return 1;
+    gp->wscale = ds;
+  }
+  return 0;
+}
+
 static int make_proj(std::map<std::string, HostTensor>& t, DeviceArena& arena, const std::string& prefix, int K, int N, int fmt,
-                     LinearWeights* lw, Gemv16Weights* gw, const HostTensor* ln_g = nullptr, const HostTensor* ln_b = nullptr,
+                     LinearWeights* lw, Gemv16Weights* gw, Gemv32Weights* gp, const HostTensor* ln_g = nullptr, const HostTensor* ln_b = nullptr,
                      const float** u_out = nullptr, const float** c_out = nullptr) {
   HostTensor* w = nullptr;
   if (need(t, prefix + ".weight", {K, N}, &w)) return 1;
@@ -120,8 +138,10 @@ static int make_proj(std::map<std::string, HostTensor>& t, DeviceArena& arena, c
     float *du = nullptr, *dc = nullptr;
     if (arena.upload(u.data(), u.size(), &du) || arena.upload(c.data(), c.size(), &dc)) return 1;
     *u_out = du; *c_out = dc;
+    if (gp && upload_stream32(arena, wf.data(), N, K, true, fmt, gp)) return 1;
   } else {
     pack_gemv16_kn(buf.data(), w->data.data(), K, N);
+    if (gp && upload_stream32(arena, w->data.data(), N, K, true, fmt, gp)) return 1;
   }
   return upload_stream(arena, buf, N, K, fmt, gw);
 }
@@ -186,10 +206,12 @@ int GPTModel::finalize(std::map<std::string, HostTensor>& t, DeviceArena& arena)
     HostTensor *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
     if (need(t, p + ".ln_1.weight", {d}, &g1) || need(t, p + ".ln_1.bias", {d}, &b1)) return 1;
     if (need(t, p + ".ln_2.weight", {d}, &g2) || need(t, p + ".ln_2.bias", {d}, &b2)) return 1;
-    if (make_proj(t, arena, p + ".attn.c_attn", d, 3 * d, weight_fmt, &L.attn_l, &L.attn_g, g1, b1, &L.attn_u, &L.attn_c)) return 1;
-    if (make_proj(t, arena, p + ".attn.c_proj", d, d, weight_fmt, &L.proj_l, &L.proj_g)) return 1;
-    if (make_proj(t, arena, p + ".mlp.c_fc", d, f, weight_fmt, &L.fc_l, &L.fc_g, g2, b2, &L.fc_u, &L.fc_c)) return 1;
-    if (make_proj(t, arena, p + ".mlp.c_proj", f, d, weight_fmt, &L.fc2_l, &L.fc2_g)) return 1;
+    Gemv32Weights* const no32 = nullptr;
+    const bool p32 = weight_fmt != WFMT_F32 && d % 32 == 0;
+    if (make_proj(t, arena, p + ".attn.c_attn", d, 3 * d, weight_fmt, &L.attn_l, &L.attn_g, p32 ? &L.attn_p : no32, g1, b1, &L.attn_u, &L.attn_c)) return 1;
+    if (make_proj(t, arena, p + ".attn.c_proj", d, d, weight_fmt, &L.proj_l, &L.proj_g, p32 ? &L.proj_p : no32)) return 1;
+    if (make_proj(t, arena, p + ".mlp.c_fc", d, f, weight_fmt, &L.fc_l, &L.fc_g, p32 ? &L.fc_p : no32, g2, b2, &L.fc_u, &L.fc_c)) return 1;
+    if (make_proj(t, arena, p + ".mlp.c_proj", f, d, weight_fmt, &L.fc2_l, &L.fc2_g, p32 ? &L.fc2_p : no32)) return 1;
   }
   if (upload(t, arena, "gpt.ln_f.weight", {d}, &lnf_g) || upload(t, arena, "gpt.ln_f.bias", {d}, &lnf_b)) return 1;
   if (upload(t, arena, "final_norm.weight", {d}, &fn_g) || upload(t, arena, "final_norm.bias", {d}, &fn_b)) return 1;
@@ -199,6 +221,7 @@ int GPTModel::finalize(std::map<std::string, HostTensor>& t, DeviceArena& arena)
   std::vector<float> buf(gemv16_packed_floats(V, d));
   pack_gemv16_nk(buf.data(), hw->data.data(), V, d);
   if (upload_stream(arena, buf, V, d, weight_fmt, &head_g)) return 1;
+  if (weight_fmt != WFMT_F32 && d % 32 == 0 && upload_stream32(arena, hw->data.data(), V, d, false, weight_fmt, &head_p)) return 1;
   if (upload(t, arena, "mel_head.bias", {V}, &head_b)) return 1;
   if (upload(t, arena, "mel_embedding.weight", {V, d}, &mel_emb)) return 1;
   if (upload(t, arena, "text_embedding.weight", {cfg.number_text_tokens + 1, d}, &text_emb)) return 1;
@@ -239,7 +262,15 @@ GPTModel::Buffers GPTModel::carve(void* ws, int B, int S, int max_new) const {
   b.hd = c.take<float>(frag_image_floats(B, d));
   b.attd = c.take<float>(frag_image_floats(B, d));
   b.ffd = c.take<float>(frag_image_floats(B, 4 * d));
+  b.pl_cnt = c.take<unsigned>((size_t)cdiv(std::max(V, 4 * d), 16));      // (arrival counters of the plane GEMV: part of the zeroed region)
   b.frag_bytes = c.off - b.frag_off;
+  b.xrow = c.take<float>((size_t)B * d);
+  b.hrow = c.take<float>((size_t)B * d);
+  b.attrow = c.take<float>((size_t)B * d);
+  b.ffrow = c.take<float>((size_t)B * 4 * d);
+  b.stats = c.take<float>((size_t)cdiv(d, 16) * cdiv(B, 16) * 16 * 2);
+  b.pl_slab = c.take<float>(std::max({gemv_pl_slab_floats(3 * d, d, B), gemv_pl_slab_floats(d, d, B), gemv_pl_slab_floats(4 * d, d, B),
+                                      gemv_pl_slab_floats(d, 4 * d, B), gemv_pl_slab_floats(V, d, B), (size_t)64}));
   b.qkvd = c.take<float>((size_t)B * 3 * d);
   b.slab = c.take<float>((size_t)8 * B * d);
   b.logits = c.take<float>((size_t)B * V);
@@ -307,19 +338,31 @@ static thread_local int tl_forced_ld = 0;      // keys the eager decode step in 
 int GPTModel::head_and_sample(const Buffers& w, int B, const float* x, int ldx, bool x_frag, float penalty, long long* codes,
                               int codes_ld, float* logits_out, hipStream_t st) {
   const int V = cfg.number_mel_codes, d = cfg.model_dim;
+  const bool pl = use_pl(B);
   RowsNormArgs n;
-  n.x_in = x; n.ld_in = ldx; n.in_frag = x_frag ? 1 : 0; n.y = w.hd; n.ld_y = d; n.y_frag = 1; n.M = B; n.d = d;
+  n.x_in = x; n.ld_in = ldx; n.in_frag = x_frag ? 1 : 0; n.M = B; n.d = d;
+  if (pl) { n.y = w.hrow; n.ld_y = d; } else { n.y = w.hd; n.ld_y = d; n.y_frag = 1; }
   n.mode = NORM_LN_LN; n.g1 = lnf_g; n.b1 = lnf_b; n.g2 = fn_g; n.b2 = fn_b;
   if (rows_norm_forward(n, st)) return 1;
-  GemvFXArgs hv;
-  hv.xf = w.hd; hv.rows = B; hv.bias = head_b; hv.y = w.logits; hv.ldy = V;
-  if (gemv_fx_forward(head_g, hv, st)) return 1;
+  if (pl) {
+    GemvPLArgs hv;
+    hv.x = w.hrow; hv.ldx = d; hv.rows = B; hv.bias = head_b; hv.y = w.logits; hv.ldy = V; hv.slab = w.pl_slab; hv.counters = w.pl_cnt;
+    if (gemv_pl_forward(head_p, hv, st)) return 1;
+  } else {
+    GemvFXArgs hv;
+    hv.xf = w.hd; hv.rows = B; hv.bias = head_b; hv.y = w.logits; hv.ldy = V;
+    if (gemv_fx_forward(head_g, hv, st)) return 1;
+  }
   if (tl_beam) return beam_scores_forward(*tl_beam, st) || beam_select_forward(*tl_beam, st) || beam_reorder_forward(*tl_beam, st);
   SampleArgs s;
   s.part = w.logits; s.parts = 1; s.part_rows = B; s.bias = nullptr; s.logits_out = logits_out;
   s.seen = w.seen; s.finished = w.finished; s.codes = codes; s.codes_ld = codes_ld; s.cur_tok = w.cur_tok;
   s.st = w.state; s.B = B; s.V = V; s.stop_token = cfg.stop_mel_token; s.penalty = penalty;
   s.forced = tl_forced; s.forced_ld = tl_forced_ld;
+  if (fused_tail(B)) {      // the sampler's workgroups also write the next step's input and advance the step scalars
+    s.embed.x_row = w.xrow; s.embed.x_stats = w.stats; s.embed.mel_emb = mel_emb; s.embed.mel_pos = mel_pos; s.embed.d = d;
+    s.embed.st_rw = w.state;
+  }
   if (samp.mode != 0) {
     SampleWarpArgs sw;
     sw.base = s; sw.mode = samp.mode; sw.temperature = samp.temperature; sw.top_k = samp.top_k; sw.top_p = samp.top_p;
@@ -332,8 +375,53 @@ int GPTModel::head_and_sample(const Buffers& w, int B, const float* x, int ldx, 
 // one autoregressive step for all B rows (replayable: no host-dependent arguments); 5 launches per layer, every
 // activation a fragment image:  c_attn [LN1 folded] -> attention -> c_proj (+x, in place) -> c_fc [LN2 folded, gelu_new]
 // -> mlp.c_proj (+x, in place)
+// The decode step runs on the plane GEMV from idxtts_set_decode_plane_rows() rows on (default 17: two or more MFMA row tiles -- merged
+// requests, 16 utterances x 3 beams).  Measured on the full-size model, 256 tokens, graph replay: 16 rows 0.328 s against 0.303 s on the
+// fp32-MFMA GEMV (its single-round-trip launches win), 32 rows 0.432 / 0.432, 48 rows 0.567 / 0.612 (profiles/README.md "Round 4").
+bool GPTModel::use_pl(int B) const { return weight_fmt != WFMT_F32 && B >= get_decode_plane_rows() && cfg.model_dim % 32 == 0 && head_p.wp; }
+bool GPTModel::fused_tail(int B) const { return use_pl(B) && samp.mode == 0 && !tl_beam; }
+
+// The decode step on the plane GEMV (gemv_pl.hip): the same five launches per layer, every activation a plain fp32 row-major matrix
+// (split into bf16 planes inside the GEMV), the residual stream updated in place, the LayerNorm statistics handed from producer to consumer; greedy generations close the
+// step with ONE launch (sample + next embedding + advance).
+int GPTModel::decode_step_pl(const Buffers& w, int B, float penalty, long long* codes, int codes_ld, float* logits_base, hipStream_t st) {
+  const int d = cfg.model_dim, T = d / 16;
+  const size_t per_layer = kv_layer_bytes(B, w.Smax);
+  const bool fused = fused_tail(B);
+  if (!fused && embed_step_pl(w.xrow, w.stats, B, d, mel_emb, mel_pos, w.cur_tok, w.state, st)) return 1;
+  for (int li = 0; li < cfg.layers; ++li) {
+    const GPTLayer& L = layers[li];
+    GemvPLArgs qa;      // qkv = c_attn(LN1(x)) + b, row-major for the attention kernel
+    qa.x = w.xrow; qa.ldx = d; qa.rows = B; qa.colsum = L.attn_u; qa.bias = L.attn_c; qa.stats_in = w.stats; qa.stats_tiles = T;
+    qa.y = w.qkvd; qa.ldy = 3 * d; qa.slab = w.pl_slab; qa.counters = w.pl_cnt;
+    if (gemv_pl_forward(L.attn_p, qa, st)) return 1;
+    DecodeAttnArgs da;
+    da.qkv_part = w.qkvd; da.parts = 1; da.part_rows = B; da.qkv_bias = nullptr;
+    da.kcache = w.kcache + li * per_layer; da.vcache = w.vcache + li * per_layer; da.kv16 = kv_fmt; da.out_row = w.attrow; da.kstart = w.kstart;
+    da.st = w.state; da.B = B; da.H = cfg.heads; da.Smax = w.Smax; da.d = d; da.scale = 0.125f;
+    da.nsplit = decode_attn_nsplit(B, cfg.heads); da.part = w.attn_part; da.cnt = w.attn_cnt;
+    da.pos_hint = tl_prof_pos;
+    if (decode_attn_forward(da, st)) return 1;
+    GemvPLArgs pa;      // x += c_proj(attn) + b (in place: a lane reads and writes only its own elements of x), + the row statistics of the new x
+    pa.x = w.attrow; pa.ldx = d; pa.rows = B; pa.bias = L.proj_l.bias; pa.res = w.xrow; pa.y = w.xrow; pa.ldy = d; pa.stats_out = w.stats;
+    pa.slab = w.pl_slab; pa.counters = w.pl_cnt;
+    if (gemv_pl_forward(L.proj_p, pa, st)) return 1;
+    GemvPLArgs fa;      // ff = gelu_new(c_fc(LN2(x)) + b)
+    fa.x = w.xrow; fa.ldx = d; fa.rows = B; fa.colsum = L.fc_u; fa.bias = L.fc_c; fa.stats_in = w.stats; fa.stats_tiles = T; fa.act = 1; fa.y = w.ffrow; fa.ldy = 4 * d;
+    fa.slab = w.pl_slab; fa.counters = w.pl_cnt;
+    if (gemv_pl_forward(L.fc_p, fa, st)) return 1;
+    GemvPLArgs fb;      // x += mlp.c_proj(ff) + b
+    fb.x = w.ffrow; fb.ldx = 4 * d; fb.rows = B; fb.bias = L.fc2_l.bias; fb.res = w.xrow; fb.y = w.xrow; fb.ldy = d; fb.stats_out = w.stats;
+    fb.slab = w.pl_slab; fb.counters = w.pl_cnt;
+    if (gemv_pl_forward(L.fc2_p, fb, st)) return 1;
+  }
+  if (head_and_sample(w, B, w.xrow, d, false, penalty, codes, codes_ld, logits_base, st)) return 1;
+  return fused ? 0 : advance_state(w.state, st);
+}
+
 int GPTModel::decode_step(const Buffers& w, int B, float penalty, long long* codes, int codes_ld, float* logits_base,
                           hipStream_t st) {
+  if (use_pl(B)) return decode_step_pl(w, B, penalty, codes, codes_ld, logits_base, st);
   const int d = cfg.model_dim;
   const size_t per_layer = kv_layer_bytes(B, w.Smax);
   if (embed_step(w.xd, B, d, mel_emb, mel_pos, w.cur_tok, w.state, st)) return 1;
@@ -443,7 +531,7 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
   {
     // last position of every row
     if (head_and_sample(w, B, w.x + (size_t)(S - 1) * d, S * d, false, penalty, codes, max_new, logits_out, st)) return 1;
-    if (advance_state(w.state, st)) return 1;
+    if (!fused_tail(B) && advance_state(w.state, st)) return 1;      // (the fused sampler of the plane-GEMV path has advanced already)
   }
 
   // ---- decode ----
@@ -467,7 +555,7 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
       std::lock_guard<std::mutex> l(graph_mu);
       for (size_t i = 0; i < graph_cache.size(); ++i) {
         GraphSlot& g = graph_cache[i];
-        if (!g.in_use && g.ws == ws && g.ws_bytes == ws_bytes && g.B == B && g.S == S && g.max_new == max_new && g.penalty == penalty && g.kv16 == kv_fmt && g.geom == get_decode_geometry()) {
+        if (!g.in_use && g.ws == ws && g.ws_bytes == ws_bytes && g.B == B && g.S == S && g.max_new == max_new && g.penalty == penalty && g.kv16 == kv_fmt && g.geom == (get_decode_geometry() | (get_decode_plane_rows() << 1))) {
           g.in_use = true; g.stamp = ++graph_stamp; exec = g.exec; lease.m = this; lease.idx = (int)i;
           break;
         }
@@ -495,7 +583,7 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
           GraphSlot& g = graph_cache[slot];
           if (g.exec) (void)hipGraphExecDestroy(g.exec);
           if (g.graph) (void)hipGraphDestroy(g.graph);
-          g.ws = ws; g.ws_bytes = ws_bytes; g.B = B; g.S = S; g.max_new = max_new; g.penalty = penalty; g.kv16 = kv_fmt; g.geom = get_decode_geometry();
+          g.ws = ws; g.ws_bytes = ws_bytes; g.B = B; g.S = S; g.max_new = max_new; g.penalty = penalty; g.kv16 = kv_fmt; g.geom = get_decode_geometry() | (get_decode_plane_rows() << 1);
           g.graph = gg.graph; g.exec = gg.exec; g.stamp = ++graph_stamp; g.in_use = true;
           gg.graph = nullptr; gg.exec = nullptr;
           lease.m = this; lease.idx = slot;

@@ -24,7 +24,7 @@ SYMBOLS = [
     "idxtts_gpt_create", "idxtts_gpt_quantize_weights", "idxtts_gpt_set_kv_format", "idxtts_gpt_get_kv_format", "idxtts_gpt_workspace_bytes", "idxtts_gpt_embed", "idxtts_gpt_generate", "idxtts_gpt_generate_forced", "idxtts_gpt_generate_sampled", "idxtts_gpt_latent",
     "idxtts_gpt_beam_workspace_bytes", "idxtts_gpt_generate_beam",
     "idxtts_s2mel_create", "idxtts_s2mel_cond_workspace_bytes", "idxtts_s2mel_prepare_cond",
-    "idxtts_s2mel_cfm_workspace_bytes", "idxtts_s2mel_cfm", "idxtts_set_gemm_mode", "idxtts_get_gemm_mode", "idxtts_set_decode_geometry", "idxtts_get_decode_geometry", "idxtts_s2mel_set_overlap", "idxtts_s2mel_get_overlap",
+    "idxtts_s2mel_cfm_workspace_bytes", "idxtts_s2mel_cfm", "idxtts_set_gemm_mode", "idxtts_get_gemm_mode", "idxtts_set_decode_geometry", "idxtts_get_decode_geometry", "idxtts_set_decode_plane_rows", "idxtts_get_decode_plane_rows", "idxtts_s2mel_set_overlap", "idxtts_s2mel_get_overlap",
     "idxtts_s2mel_estimator", "idxtts_s2mel_regulate", "idxtts_cond_create", "idxtts_cond_workspace_bytes", "idxtts_cond_forward", "idxtts_emovec_merge",
     "idxtts_gpt_graph_cache_entries", "idxtts_w2vbert_create", "idxtts_w2vbert_workspace_bytes", "idxtts_w2vbert_forward",
     "idxtts_repcodec_create", "idxtts_repcodec_workspace_bytes", "idxtts_repcodec_quantize",
@@ -319,6 +319,16 @@ def set_decode_geometry(narrow: bool) -> None:
 
 def get_decode_geometry() -> bool:
     return bool(load().idxtts_get_decode_geometry())
+
+
+def set_decode_plane_rows(min_rows: int) -> None:
+    """From how many decode rows on (compact weight streams) the decode step runs on the plane GEMV (include/idxtts.h): 0 = default (17),
+    5..64, 65 = off.  Process-wide; set before generating."""
+    check(load().idxtts_set_decode_plane_rows(int(min_rows)))
+
+
+def get_decode_plane_rows() -> int:
+    return int(load().idxtts_get_decode_plane_rows())
 
 
 def set_s2mel_overlap(on: bool) -> None:

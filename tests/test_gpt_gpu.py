@@ -583,3 +583,129 @@ def test_bf16_kv_cache_beam_sample_vs_oracle(device):
             want = og.generate_beam(tw, cfg, og.conds_latent(tw, cfg, lat, emo), text, NEW, noise, num_beams=NB, do_sample=do_sample, kv_round=True)
         got = codes.cpu().numpy()
         assert got.shape == tuple(want.shape) and np.array_equal(got, want.numpy()), do_sample
+
+
+@pytest.fixture
+def plane_from_5_rows():
+    """The plane GEMV from 5 decode rows on (default: 17), so that its one-row-tile geometry is exercised too."""
+    from indextts_amd import _lib
+    _lib.set_decode_plane_rows(5)
+    yield
+    _lib.set_decode_plane_rows(0)
+    assert _lib.get_decode_plane_rows() == 17
+
+
+def _pl_model(device, fmt, heads=2, kv="bf16", tag="t/gpt/pl", V=210, stop_bias=0.0):
+    from indextts_amd.gpt import UnifiedVoice
+    cfg = GPTConfig(model_dim=64 * heads, heads=heads, layers=3, number_mel_codes=V, number_text_tokens=60, start_mel_token=V - 2, stop_mel_token=V - 1,
+                    max_mel_tokens=80, max_text_tokens=30)
+    w = weights.synth_gpt_weights(cfg, tag=f"{tag}/{fmt}/{heads}")
+    w["mel_head.bias"] = w["mel_head.bias"].copy()
+    w["mel_head.bias"][cfg.stop_mel_token] += stop_bias
+    uv = UnifiedVoice(w, cfg, device=device, weight_format=fmt, keep_effective=True, kv_format=kv)
+    return cfg, uv, {k: torch.from_numpy(v) for k, v in uv.effective_state_dict.items()}
+
+
+def _assert_equal_or_near_tie(got, ref, ref_logits, fake, tol, penalty=10.0):
+    """Greedy codes equal the oracle's, or a row leaves the oracle's sequence at a step where the ORACLE's own margin between its token
+    and the row's token is below `tol` (the bf16 KV cache adds ~2e-3 of noise to a logit: a key / value one ulp apart between two fp32
+    summation orders may round to the other bf16 neighbour; oracle/parity.py measures it at full size)."""
+    from oracle import gpt as og
+    got, ref = np.asarray(got), np.asarray(ref)
+    n = min(got.shape[1], ref.shape[1])
+    flips = 0
+    for b in range(ref.shape[0]):
+        d = np.nonzero(got[b, :n] != ref[b, :n])[0]
+        if len(d) == 0:
+            continue
+        s = int(d[0])
+        ids = torch.cat([fake[b], torch.from_numpy(ref[b, :s].astype(np.int64))])[None]
+        sc = og.repetition_penalty(ids, ref_logits[b, s][None].float(), penalty)[0]
+        margin = float(sc[int(ref[b, s])] - sc[int(got[b, s])])
+        assert 0.0 <= margin <= tol, f"row {b} leaves the oracle at step {s} where its margin is {margin:.3e} (> {tol})"
+        flips += 1
+    return flips
+
+
+@pytest.mark.parametrize("fmt,B,heads", [("bf16", 5, 2), ("bf16", 16, 2), ("bf16", 20, 3), ("bf16", 48, 2), ("bf16", 64, 2), ("fp8", 6, 2), ("fp8", 33, 3), ("fp8", 64, 2)])
+def test_plane_gemv_decode_rows_vs_oracle(device, plane_from_5_rows, fmt, B, heads):
+    """Compact weight streams with more than 4 decode rows run the decode step on the bf16-MFMA plane GEMV (csrc/gemv_pl.hip: activations
+    as three bf16 planes, K split over waves and workgroups, LayerNorm statistics handed over per 16 columns, sample + embed + advance
+    in one launch): 1-4 row tiles, both formats, d = 128 / 192 (K not a multiple of the workgroup's K part), ragged texts, a stop
+    bias so that rows finish at different steps -- greedy codes bit-exact against the oracle on the read-back rounded model, per-step
+    logits within the fp32 tolerance, graph replay == eager launches, and both KV formats."""
+    from oracle import gpt as og
+    cfg, uv, tw = _pl_model(device, fmt, heads, stop_bias=1.2)
+    L, NEW = 9, 30
+    lat = torch.from_numpy(synth.uniform("t/gpt/pl/lat", (B, cfg.cond_latents, cfg.model_dim), 0.5))
+    emo = torch.from_numpy(synth.uniform("t/gpt/pl/emo", (B, cfg.model_dim), 0.3))
+    text = torch.from_numpy(synth.integers("t/gpt/pl/text", (B, L), 2, cfg.number_text_tokens))
+    for b in range(B):
+        text[b, L - (b % 4):] = cfg.stop_text_token
+    conds = og.conds_latent(tw, cfg, lat, emo)
+    fake = og.prepare_gpt_inputs(tw, cfg, conds, text)[0]
+    for kv in ("bf16", "f32"):
+        uv.set_kv_format(kv)
+        with torch.no_grad():
+            ref, ref_logits = og.generate_greedy(tw, cfg, conds, text, NEW, 10.0, return_logits=True, kv_round=kv == "bf16")
+        codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, repetition_penalty=10.0)
+        if kv == "f32":      # nothing is rounded between the weights and the logits: bit-exact codes
+            assert np.array_equal(codes.cpu().numpy(), ref.numpy()), kv
+        else:                # bf16 cache: equal, or parted at a near-tie of the oracle (at most a row or two of a batch)
+            assert _assert_equal_or_near_tie(codes.cpu().numpy(), ref.numpy(), ref_logits, fake, 1e-2) <= max(1, B // 16)
+        eager, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, repetition_penalty=10.0, use_graph=False)
+        assert torch.equal(eager, codes)
+        # per-step logits on the ORACLE's tokens (teacher-forced: a row that parted at a tie would compare two different sequences)
+        n = ref.shape[1]
+        forced = torch.full((B, NEW), cfg.stop_mel_token, dtype=torch.long)
+        forced[:, :n] = ref
+        _, _, logits = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, repetition_penalty=10.0, return_logits=True, forced_codes=forced)
+        tol = 5e-5 if kv == "f32" else 1e-2
+        assert (logits.cpu()[:, :n] - ref_logits).abs().max().item() <= tol, kv
+    uv.set_kv_format("bf16")
+
+
+def test_plane_gemv_rows_do_not_depend_on_the_batch(device, plane_from_5_rows):
+    """Row b of a 60-row decode (4 row tiles: 8 column tiles per workgroup) equals, bit for bit in every logit, the same utterance decoded
+    in a 44-row and a 46-row batch (3 row tiles, 4 column tiles per workgroup; different positions inside the tiles): the plane GEMV's
+    arithmetic per row depends neither on the batch nor on the geometry the batch selects --
+    what lets serving.BatchPipeline merge waiting requests into one decode.  (3 heads: every batch here has more than 128 (utterance,
+    head) pairs, so the decode attention never splits its keys -- the one kernel whose summation order follows the batch size.)"""
+    cfg, uv, tw = _pl_model(device, "bf16", 3)
+    B, L, NEW = 60, 8, 16
+    lat = torch.from_numpy(synth.uniform("t/gpt/plb/lat", (B, cfg.cond_latents, cfg.model_dim), 0.5))
+    emo = torch.from_numpy(synth.uniform("t/gpt/plb/emo", (B, cfg.model_dim), 0.3))
+    text = torch.from_numpy(synth.integers("t/gpt/plb/text", (B, L), 2, cfg.number_text_tokens))
+    full, _, lg = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, repetition_penalty=10.0, return_logits=True)
+    for lo, hi in ((0, 44), (14, 60)):
+        part, _, lp = uv.inference_speech(lat[lo:hi], text[lo:hi], emo_vec=emo[lo:hi], max_generate_length=NEW, repetition_penalty=10.0, return_logits=True)
+        n = min(part.shape[1], full.shape[1])
+        assert torch.equal(part[:, :n], full[lo:hi, :n]) and torch.equal(lp[:, :n], lg[lo:hi, :n]), (lo, hi)
+
+
+@pytest.mark.parametrize("fmt", ["bf16", "fp8"])
+def test_plane_gemv_sampling_and_beams_vs_oracle(device, plane_from_5_rows, fmt):
+    """The plane-GEMV decode step under the other decoding modes (separate embed / sampler / advance launches): HF multinomial sampling
+    on 6 rows and beam-sample / beam search on 4 utterances x 3 beams = 12 rows, tokens bit-exact against the oracle."""
+    from oracle import gpt as og
+    cfg, uv, tw = _pl_model(device, fmt, 2, tag="t/gpt/pls", V=90)
+    B, L, NEW, NB = 6, 9, 14, 3
+    lat = torch.from_numpy(synth.uniform("t/gpt/pls/lat", (B, cfg.cond_latents, cfg.model_dim), 0.5))
+    emo = torch.from_numpy(synth.uniform("t/gpt/pls/emo", (B, cfg.model_dim), 0.3))
+    text = torch.from_numpy(synth.integers("t/gpt/pls/text", (B, L), 2, cfg.number_text_tokens))
+    gen = torch.Generator().manual_seed(3)
+    noise = torch.stack([torch.empty(B, cfg.number_mel_codes).exponential_(1, generator=gen) for _ in range(NEW)])
+    conds = og.conds_latent(tw, cfg, lat, emo)
+    with torch.no_grad():
+        want = og.generate_sample(tw, cfg, conds, text, NEW, noise, 10.0, 0.8, 30, 0.8, kv_round=True)
+    codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, do_sample=True, top_p=0.8, top_k=30, temperature=0.8,
+                                   repetition_penalty=10.0, exp_noise=noise)
+    assert np.array_equal(codes.cpu().numpy(), want.numpy())
+    Bb = 4
+    bnoise = torch.empty(NEW, Bb, NB * cfg.number_mel_codes).exponential_(1.0, generator=gen)
+    for do_sample in (True, False):
+        with torch.no_grad():
+            wb = og.generate_beam(tw, cfg, conds[:Bb], text[:Bb], NEW, bnoise, num_beams=NB, do_sample=do_sample, kv_round=True)
+        cb, _ = uv.inference_speech(lat[:Bb], text[:Bb], emo_vec=emo[:Bb], max_generate_length=NEW, num_beams=NB, do_sample=do_sample, top_p=0.8, top_k=30,
+                                    temperature=0.8, repetition_penalty=10.0, length_penalty=0.0, exp_noise=bnoise)
+        assert cb.shape == tuple(wb.shape) and np.array_equal(cb.cpu().numpy(), wb.numpy()), do_sample
