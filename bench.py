@@ -47,7 +47,7 @@ LOGIT_NOISE_BOUND = {"f32": 1e-4, "bf16": 1.5e-2}
 # the rows of profiles/rNN_*_kernel_stats.csv whose name contains it.
 MFMA_KERNELS = ("conv1d_mfma_kernel", "conv1d_bf16x3_kernel", "gemm_tn_kernel", "gemm_bf16x3", "flash_attn")
 SPLIT_BF16_KERNELS = ("conv1d_bf16x3_kernel", "gemm_bf16x3", "flash_attn_bf16x3_kernel", "flash_attn_planes_kernel")
-DECODE_KERNELS = ("gemv_fx_kernel", "gemv_fx_combine_kernel", "decode_attn_kernel", "decode_attn16_kernel", "sample_greedy_kernel", "sample_warp_kernel", "embed_step_kernel",
+DECODE_KERNELS = ("gemv_fx_kernel", "gemv_pl_kernel", "gemv_fx_combine_kernel", "decode_attn_kernel", "decode_attn16_kernel", "sample_greedy_kernel", "sample_warp_kernel", "embed_step_kernel",
                   "advance_state_kernel", "beam_")
 
 
@@ -120,6 +120,11 @@ def roofline_from_profile(prof, steps, workload="pipeline", split_bf16=True, def
 def _lib_geometry():
     from indextts_amd import _lib
     return _lib.get_decode_geometry()
+
+
+def _lib_plane_rows():
+    from indextts_amd import _lib
+    return _lib.get_decode_plane_rows()
 
 
 def stage_rooflines(stages, prof, nprof, B, L, M, Tp, Tg, n_cfm, w_bytes_per_param, kv_bytes=4):
@@ -385,6 +390,7 @@ def build_pipeline(args, world, rank, dev):
                         + ("" if not kv16 else ", KV cache stored as bf16 (keys / values rounded once when produced; fp32 arithmetic)"),
             "gpt_weights": args.gpt_weights, "gpt_kv_cache": tts.gpt.kv_format,
             "decode_geometry": "narrow (512-thread GEMV workgroups)" if _lib_geometry() else "wide (1024-thread GEMV workgroups)",
+            "decode_plane_rows": _lib_plane_rows(),
             "batch_per_gpu": B, "text_tokens": L, "codes": M, "prompt_frames": Tp, "diffusion_steps": cfg.diffusion_steps}
     desc["step_overlap"] = ("none" if args.no_overlap else
                             f"software pipeline across steps: {lanes} decode chain(s) in flight (one stream + host thread each"
@@ -527,6 +533,8 @@ def main() -> int:
     ap.add_argument("--decode-geometry", default="auto", choices=["auto", "wide", "narrow"],
                     help="decode GEMVs as 1024-thread (wide) or 512-thread (narrow) workgroups (idxtts_set_decode_geometry): auto = narrow for the "
                          "pipelined run, whose decode launches have to find room beside the acoustic stage's kernels, wide with --no-overlap")
+    ap.add_argument("--plane-rows", type=int, default=0, help="decode rows from which the plane GEMV runs the decode step (idxtts_set_decode_plane_rows; "
+                                                              "0 = the library default 17, or 5 with --coalesce > 1)")
     ap.add_argument("--gpt-kv", default=None, choices=["f32", "bf16"],
                     help="storage of the GPT's KV cache: default bf16 with compact weights (the reference's use_fp16 halves weights and cache "
                          "together), f32 with --gpt-weights f32; keys / values are rounded once when produced, arithmetic stays fp32, and the "
@@ -577,6 +585,10 @@ def main() -> int:
     _lib.set_s2mel_overlap(bool(args.s2mel_overlap))
     narrow = args.decode_geometry == "narrow" or (args.decode_geometry == "auto" and args.workload == "pipeline" and not args.no_overlap)
     _lib.set_decode_geometry(narrow)
+    if args.plane_rows:
+        _lib.set_decode_plane_rows(args.plane_rows)
+    elif args.coalesce > 1:
+        _lib.set_decode_plane_rows(5)      # merged decodes run on the plane GEMV: the 16-row requests have to run on it alone too (serving.merge_keeps_kernels)
     t0 = time.time()
     build = build_pipeline if args.workload == "pipeline" else (build_prompt_or_infer if side else build_vocoder)
     step, profiled, cpu_leg, stage_times_fn, audio_s_per_step_per_gpu, desc = build(args, world, rank, dev)

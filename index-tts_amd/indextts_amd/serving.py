@@ -14,9 +14,13 @@ prompt and text width and decodes them as ONE batch (a decode step streams the 9
 
 Every request is computed exactly as `synthesize_batch` computes it: the kernels treat the rows of a batch independently (same
 arithmetic and summation order per row whatever the batch size: tests/test_serving_gpu.py, and bench.py compares every retired
-batch with the sequential call bit for bit), so only the interleaving on the device changes.  (One caveat for merged decodes:
-which GEMM kernel a launch runs on depends on its row count -- split-bf16 from 256 rows up -- so a request of a few dozen GEMM rows
-could change kernels when merged; any real utterance is hundreds of rows on its own.)
+batch with the sequential call bit for bit), so only the interleaving on the device changes.  Two launches pick their KERNEL by
+row count, though, and a merge must not move a request across either threshold (`merge_keeps_kernels`, enforced in `_take`):
+the GEMM-shaped passes run split-bf16 from 256 rows up (a request of a few dozen prefill rows would change kernels when merged --
+what made `test_batch_pipeline_equals_sequential[2-3-2]` differ from the sequential call at the 1e-4 level in round 3, on toy
+requests of 38-76 rows; any real utterance is hundreds of rows on its own), and the decode step runs on the plane GEMV from
+`idxtts_set_decode_plane_rows()` rows on (default 17) -- so 16-utterance requests merge only where the plane GEMV also decodes
+them alone (`_lib.set_decode_plane_rows(5)`, once per process), or where the merged batch stays below the threshold.
 
 Measured at configs[2] (profiles/README.md "Round 3"): decode chains and acoustic stages SHARING the device give the same
 throughput as strict turns (3 decodes together, then their 3 acoustic stages: 163 vs 165 audio-s/s) -- a decode launch that needs
@@ -39,6 +43,26 @@ import time
 from typing import Optional
 
 import torch
+
+
+def merge_keeps_kernels(rows_each, prefix_len: int, split_bf16_gemm: bool, compact_weights: bool, plane_rows: int) -> bool:
+    """May requests of `rows_each` utterances (same text width; `prefix_len` = conditioning + text rows of one utterance's prompt) be
+    decoded as ONE batch and still equal their own sequential calls bit for bit?  Rows are independent inside every kernel; what a merge
+    can change is WHICH kernel runs:
+      * GEMM-shaped passes (prefill, latent pass): exact fp32 below 256 rows, split-bf16 from 256 rows on (csrc/gemm.hip dispatch) --
+        every request must be on the split-bf16 side by itself (its prefill alone has >= 256 rows), unless the exact mode is selected;
+      * the decode step with compact weight streams: fp32-MFMA GEMV below `plane_rows` rows, plane GEMV from there on
+        (idxtts_set_decode_plane_rows) -- all requests and the merged batch must fall on the same side."""
+    rows_each = [int(r) for r in rows_each]
+    if len(rows_each) <= 1:
+        return True
+    if split_bf16_gemm and any(r * prefix_len < 256 for r in rows_each):
+        return False
+    if compact_weights:
+        total = sum(rows_each)
+        if not (total < plane_rows or min(rows_each) >= plane_rows):
+            return False
+    return True
 
 
 class _Request:
@@ -101,9 +125,16 @@ class BatchPipeline:
             if not self._queue:
                 return []
             group = [self._queue.popleft()]
-            while len(group) < self.coalesce and self._queue and group[0].compatible(self._queue[0]):
+            while len(group) < self.coalesce and self._queue and group[0].compatible(self._queue[0]) and self._keeps_kernels(group + [self._queue[0]]):
                 group.append(self._queue.popleft())
             return group
+
+    def _keeps_kernels(self, group) -> bool:
+        from . import _lib
+        g = self.tts.cfg.gpt
+        prefix = g.cond_latents + 2 + int(group[0].text.shape[1]) + 2 + 1      # [cond | start, text, stop] + start_mel (gpt.py::prepare_gpt_inputs)
+        return merge_keeps_kernels([r.text.shape[0] for r in group], prefix, _lib.get_gemm_mode() == _lib.GEMM_BF16X3,
+                                   self.tts.gpt.weight_format != "f32", _lib.get_decode_plane_rows())
 
     def _lane_job(self):
         group = self._take()

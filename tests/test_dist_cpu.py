@@ -163,3 +163,18 @@ def test_synthesize_sharded_two_ranks():
     r0, r1 = results[0][2], results[1][2]
     assert [len(c) for c in r0] == [1, 1, 0, 2] and [len(c) for c in r1] == [1, 0, 0, 2]
     assert [c[0] for c in r0[3]] == [4, 2] and r0[0][0][0] == 4 and r1[0][0][0] == 3
+
+
+def test_merge_keeps_kernels_rule():
+    """serving.merge_keeps_kernels: a decode merge is allowed only where every request runs the same kernels merged as alone."""
+    from indextts_amd.serving import merge_keeps_kernels as ok
+    # real requests: 16 utterances x (34 + 128 + 3) prompt rows -- far above the 256-row GEMM threshold
+    assert ok([16, 16, 16], 165, True, False, 17)                     # fp32 weights: one decode family
+    assert not ok([16, 16, 16], 165, True, True, 17)                  # compact weights: 16 alone = fp32-MFMA GEMV, 48 merged = plane GEMV
+    assert ok([16, 16, 16], 165, True, True, 5)                       # plane GEMV from 5 rows on: same family alone and merged
+    assert ok([4, 4, 4], 165, True, True, 17) and not ok([4, 4, 4, 8], 165, True, True, 17)     # 12 rows stay below 17, 20 do not
+    assert ok([32, 32], 165, True, True, 17)                          # both sides on the plane GEMV already
+    # round 3's toy requests: 2-4 utterances x 19 prompt rows = 38-76 GEMM rows each
+    assert not ok([2, 3, 4], 19, True, False, 17)                     # split-bf16 mode: merged rows would cross 256
+    assert ok([2, 3, 4], 19, False, False, 17)                        # exact mode: no row-count dispatch
+    assert ok([7], 19, True, True, 17)

@@ -147,3 +147,79 @@ def test_fullsize_pipeline_three_lanes_equals_sequential(device):
     for k in range(nb):
         for a, b in zip(got[k], want[k]):
             assert torch.equal(a, b), k
+
+
+def test_merges_that_would_change_kernels_are_refused(device):
+    """Round 3's red `test_batch_pipeline_equals_sequential[2-3-2]`: merged toy requests (38-76 prefill rows each) crossed the 256-row
+    threshold between the exact-fp32 and the split-bf16 GEMM, so their latent pass ran on another kernel than their sequential calls
+    (1e-4 relative in the waveform).  In the default (split-bf16) mode BatchPipeline now refuses such merges (`merge_keeps_kernels`):
+    every request is decoded on its own, nothing has more rows than its request, and the results equal the sequential calls."""
+    from indextts_amd import _lib
+    from indextts_amd.infer_v2 import IndexTTS2, PromptConditioning
+    from indextts_amd.serving import BatchPipeline
+    assert _lib.get_gemm_mode() == _lib.GEMM_BF16X3
+    cfg = PipelineConfig.tiny()
+    wg = weights.synth_gpt_weights(cfg.gpt, tag="t/serve/gpt")
+    wg["mel_head.bias"] = wg["mel_head.bias"].copy()
+    wg["mel_head.bias"][cfg.gpt.stop_mel_token] = -1e4
+    tts = IndexTTS2.from_state_dicts(cfg, wg, weights.synth_s2mel_weights(cfg.s2mel, tag="t/serve/s2mel"),
+                                     weights.synth_bigvgan_weights(cfg.bigvgan, tag="t/serve/voc"), device=device)
+    cond = PromptConditioning.synthetic(cfg, prompt_frames=40, tag="t/serve/prompt").to(device)
+    nb, M = 5, 20
+    Tg = int(M * cfg.code_to_frame)
+    texts = [torch.from_numpy(synth.integers(f"t/serve/text{k}", (2 + k % 3, 9), 2, cfg.gpt.number_text_tokens)) for k in range(nb)]
+    noises = [torch.from_numpy(synth.uniform(f"t/serve/noise{k}", (t.shape[0], cfg.s2mel.in_channels, 40 + Tg), 1.0)).to(device) for k, t in enumerate(texts)]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = [tts.synthesize_batch(t, cond, max_mel_tokens=M, noise=n) for t, n in zip(texts, noises)]
+        torch.cuda.synchronize()
+        with BatchPipeline(tts, decode_lanes=1, coalesce=3) as pipe:
+            pipe.trace = []
+            got = [f.result() for f in [pipe.submit(t, cond, max_mel_tokens=M, noise=n) for t, n in zip(texts, noises)]]
+            rows = sorted(r for kind, _, _, r in pipe.trace if kind == "decode")
+    assert rows == sorted(int(t.shape[0]) for t in texts)          # one decode per request: nothing was merged
+    for k in range(nb):
+        for a, b in zip(got[k], want[k]):
+            assert torch.equal(a, b), k
+
+
+def test_fullsize_merged_48_row_decodes_equal_sequential(device):
+    """Dynamic batching where it is meant to be used: full-size model, bf16 weight streams, three 16-utterance requests decoded as ONE
+    48-row batch on the plane GEMV (the plane path selected from 5 rows on, so the sequential 16-row calls run on it too), each
+    request's acoustic stage on its own -- every waveform equals the sequential call bit for bit, and the trace shows the merge."""
+    from indextts_amd import _lib
+    from indextts_amd.infer_v2 import IndexTTS2, PromptConditioning
+    from indextts_amd.serving import BatchPipeline
+    cfg = PipelineConfig()
+    wg = weights.synth_gpt_weights(cfg.gpt, tag="bench/gpt")
+    wg["mel_head.bias"] = wg["mel_head.bias"].copy()
+    wg["mel_head.bias"][cfg.gpt.stop_mel_token] = -1e4
+    _lib.set_decode_plane_rows(5)
+    try:
+        tts = IndexTTS2.from_state_dicts(cfg, wg, weights.synth_s2mel_weights(cfg.s2mel, tag="bench/s2mel"),
+                                         weights.synth_bigvgan_weights(cfg.bigvgan, tag="bench/bigvgan"), device=device, gpt_weight_format="bf16")
+        cond = PromptConditioning.synthetic(cfg, prompt_frames=200, tag="t/serve/fullprompt").to(device)
+        nb, B, L, M = 3, 16, 24, 40
+        Tg = int(M * cfg.code_to_frame)
+        texts = [torch.from_numpy(synth.integers(f"t/serve/m48/text{k}", (B, L), 2, cfg.gpt.number_text_tokens)) for k in range(nb)]
+        noises = [torch.from_numpy(synth.uniform(f"t/serve/m48/noise{k}", (B, cfg.s2mel.in_channels, 200 + Tg), 1.5)).to(device) for k in range(nb)]
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = [tts.synthesize_batch(t, cond, max_mel_tokens=M, noise=n) for t, n in zip(texts, noises)]
+            torch.cuda.synchronize()
+            with BatchPipeline(tts, decode_lanes=1, coalesce=3) as pipe:
+                pipe.trace = []
+                # the lane is busy with a first request while the three others queue up behind it: they are taken together
+                first = pipe.submit(texts[0], cond, max_mel_tokens=M, noise=noises[0])
+                futs = [pipe.submit(t, cond, max_mel_tokens=M, noise=n) for t, n in zip(texts, noises)]
+                got = [f.result() for f in futs]
+                first.result()
+                rows = [r for kind, _, _, r in pipe.trace if kind == "decode"]
+        assert max(rows) > 16, rows
+        for k in range(nb):
+            for a, b in zip(got[k], want[k]):
+                assert torch.equal(a, b), k
+    finally:
+        _lib.set_decode_plane_rows(0)
