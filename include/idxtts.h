@@ -143,6 +143,11 @@ int idxtts_get_decode_plane_rows(void);
 int idxtts_s2mel_set_overlap(int on);
 int idxtts_s2mel_get_overlap(void);
 int idxtts_linear_destroy(idxtts_linear* lin);
+/* The library keeps a little state per caller STREAM (the split-plane scratch of the LDS-DMA GEMM; the side stream and events of
+ * idxtts_s2mel_set_overlap): a caller that retires a stream (a serving loop shutting down its worker threads) hands it back here,
+ * before destroying the stream.  Stream-ordered, no device-wide synchronisation.  No reference counterpart (torch's caching
+ * allocator plays this role there). */
+int idxtts_release_stream(void* stream);
 /* Multi-head attention, head_dim 64, softmax(q k^T * scale + mask) v without materialising the scores.
  * q/k/v/o are read in place: element (b, t, h, e) at base + b*batch_stride + t*token_stride + 64*h + e.
  * causal: key <= query.  kstart/kend: optional device int32 [B], keys outside [kstart, kend) are masked

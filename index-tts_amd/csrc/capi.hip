@@ -657,6 +657,13 @@ int idxtts_set_decode_geometry(int narrow) {
 
 int idxtts_get_decode_geometry(void) { return get_decode_geometry(); }
 
+int idxtts_release_stream(void* stream) {
+  API_BEGIN
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return gemm_release_stream_scratch(st) || s2mel_release_stream(st);
+  API_END
+}
+
 int idxtts_set_decode_plane_rows(int min_rows) {
   API_BEGIN
   IDX_CHECK(min_rows == 0 || (min_rows >= 5 && min_rows <= 65), "0 (default), 5..64 or 65 (off)");

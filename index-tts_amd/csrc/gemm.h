@@ -64,4 +64,6 @@ int gemm_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t stream);
 // true when gemm_forward would run this shape on the LDS-DMA split-bf16 kernel (the only consumer / producer of planes)
 bool gemm_uses_planes(const LinearWeights& w, const GemmArgs& a);
 
+int gemm_release_stream_scratch(hipStream_t stream);      // idxtts_release_stream: the split-plane scratch kept per stream
+
 }  // namespace idxtts

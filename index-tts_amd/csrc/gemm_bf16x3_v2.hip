@@ -355,23 +355,45 @@ static std::map<std::pair<int, hipStream_t>, PlaneScratch> g_scratch;
 static std::mutex g_scratch_mu;
 
 
+// idxtts_release_stream: drop what the library keeps for a stream that is going away
+int gemm_release_stream_scratch(hipStream_t stream) {
+  int dev_id = 0;
+  IDX_HIP(hipGetDevice(&dev_id));
+  PlaneScratch sc;
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    auto it = g_scratch.find(std::make_pair(dev_id, stream));
+    if (it == g_scratch.end()) return 0;
+    sc = it->second;
+    g_scratch.erase(it);
+  }
+  if (sc.ptr) IDX_HIP(hipFreeAsync(sc.ptr, stream));
+  return 0;
+}
+
 // p: fully prepared by gemm_bf16x3_forward (shapes, epilogue, conv parameters); planes: w.wp16 + offset
 int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w, const GemmArgs& a, hipStream_t stream, double flops,
                            double bytes) {
   IDX_CHECK(w.K % 16 == 0 && (a.taps <= 1 || (w.K / a.taps) % 16 == 0), "v2 needs K % 16 == 0");
   const int xk = a.taps > 1 ? w.K / a.taps : w.K;       // channels of the activation rows
   const size_t plane = (size_t)(xk / 16) * a.M * 16 * sizeof(__bf16);
-  std::unique_lock<std::mutex> lock(g_scratch_mu);
   int dev_id = 0;
   IDX_HIP(hipGetDevice(&dev_id));
-  PlaneScratch& sc = g_scratch[std::make_pair(dev_id, stream)];      // (map nodes are stable: the reference outlives the lock; a stream has one user)
-  if (!a.x_planes && sc.bytes < 2 * plane) {
-    IDX_HIP(hipStreamSynchronize(stream));
-    if (sc.ptr) IDX_HIP(hipFree(sc.ptr));
-    sc.bytes = 2 * plane + (plane >> 2);
-    IDX_HIP(hipMalloc(&sc.ptr, sc.bytes));
+  PlaneScratch* scp = nullptr;
+  {      // the lock covers the map only (nodes are stable and a stream has one user): growing one stream's scratch stalls nobody else
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    scp = &g_scratch[std::make_pair(dev_id, stream)];
   }
-  lock.unlock();
+  PlaneScratch& sc = *scp;
+  if (!a.x_planes && sc.bytes < 2 * plane) {
+    // stream-ordered: the old block is released behind the launches that still read it, without the device-wide synchronisation of
+    // hipFree (which would stall every decode lane and acoustic worker of a serving loop)
+    if (sc.ptr) IDX_HIP(hipFreeAsync(sc.ptr, stream));
+    sc.ptr = nullptr; sc.bytes = 0;
+    const size_t nb = 2 * plane + (plane >> 2);
+    IDX_HIP(hipMallocAsync(&sc.ptr, nb, stream));
+    sc.bytes = nb;
+  }
   const __bf16* hi = a.x_planes ? static_cast<const __bf16*>(a.x_planes) : static_cast<const __bf16*>(sc.ptr);
   const __bf16* lo = hi + plane / sizeof(__bf16);
   if (!a.x_planes) {

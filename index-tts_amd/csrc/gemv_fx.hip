@@ -171,6 +171,13 @@ int fp8_check_device_decode(hipStream_t stream) {
   return 0;
 }
 
+// Ablation masks of tools/gemv_probe.hip (built with -DGEMV_PROBE); the product build compiles every probe branch out.
+#ifdef GEMV_PROBE
+#define FX_DBG(mask) (p.dbg & (mask))
+#else
+#define FX_DBG(mask) false
+#endif
+
 struct GemvFXP {
   const float* xf;          // A-fragment images [MT][kc16][64][4]
   const void* wp;           // packed weights [ntiles][kc16][64][4] elements of the WT format
@@ -235,7 +242,7 @@ template <int MT, int NTW, bool SINGLE, int WT, bool R4, int UNS = 5>
 __global__ __launch_bounds__(UNS == 10 ? 512 : 1024) void gemv_fx_kernel(const GemvFXP p) {
   static_assert(!R4 || MT == 1, "the 4-row form has one row tile");
   typedef typename WRaw<WT>::raw wraw_t;
-  if (p.dbg & 8) return;      // tools/gemv_probe.hip: launch + dispatch cost of this geometry alone
+  if (FX_DBG(8)) return;      // tools/gemv_probe.hip: launch + dispatch cost of this geometry alone
   constexpr int UN = SINGLE ? UNS : FXCfg<MT, NTW, SINGLE>::UN;
   constexpr int NB = SINGLE ? 1 : 2;
   constexpr int NACC = MT * NTW;
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(UNS == 10 ? 512 : 1024) void gemv_fx_kernel(const G
   auto consume = [&](int buf, int cb) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      if (!(cb + u < nch) || (p.dbg & 1)) {
+      if (!(cb + u < nch) || FX_DBG(1)) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) xq[buf][u][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(UNS == 10 ? 512 : 1024) void gemv_fx_kernel(const G
       f32x4 wf[NTW];
 #pragma unroll
       for (int j = 0; j < NTW; ++j) wf[j] = WRaw<WT>::widen(wq[buf][u][j]);
-      if (p.dbg & 2) {
+      if (FX_DBG(2)) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(UNS == 10 ? 512 : 1024) void gemv_fx_kernel(const G
     }
   }
 
-  if (p.dbg & 4) {
+  if (FX_DBG(4)) {
     if (acc[0][0][0] == 123.456f) p.y[tid] = acc[0][0][1];
     return;
   }
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(UNS == 10 ? 512 : 1024) void gemv_fx_kernel(const G
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int j = 0; j < NTW; ++j) *reinterpret_cast<f32x4*>(&redbuf[((wave * NACC + mt * NTW + j) * 64 + lane) * 4]) = acc[mt][j];
-  if (ln && kwave && !(p.dbg & 16)) {
+  if (ln && kwave && !FX_DBG(16)) {
     // the four lane groups (lane >> 4) hold disjoint k of the same row: fold them, then slice mean / M2 about the mean
     const float cnt = 16.0f * nch;    // K-slice elements per row (padded chunks excluded: K % 16 == 0 for folded layers)
 #pragma unroll
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(UNS == 10 ? 512 : 1024) void gemv_fx_kernel(const G
   // slice bits adds them -- the same tree in every lane, so all lanes of a row agree bit for bit -- with the exact identity
   //   mean = sum_w n_w mean_w / n,   M2 = sum_w M2_w + sum_w n_w (mean_w - mean)^2
   float ln_mean = 0.f, ln_rstd = 0.f;
-  if (ln && e_t < NACC && !(p.dbg & 32)) {      // wave-uniform (e_t = tid >> 8); rows beyond p.rows are zero padding: harmless
+  if (ln && e_t < NACC && !FX_DBG(32)) {      // wave-uniform (e_t = tid >> 8); rows beyond p.rows are zero padding: harmless
     const int sl = lane >> 2;
     const bool on = sl < p.kw;
     const float nw = on ? 16.0f * max(0, min(p.cps, p.kc16 - sl * p.cps)) : 0.f;      // (folded LayerNorm implies ksb == 1)

@@ -105,5 +105,8 @@ struct GPTModel : ModelBase {
 
 // beam state of the generation this host thread is running (null = greedy / sampling); read by head_and_sample
 extern thread_local const BeamState* tl_beam;
+// cached positions (incl. the token in flight) of the eager decode step being launched: the profiler's byte accounting of the decode
+// attention (0 while a captured graph replays: the host does not know the position then)
+extern thread_local int tl_prof_pos;
 
 }  // namespace idxtts

@@ -330,7 +330,7 @@ int GPTModel::layer_full(int li, const Buffers& w, int B, int S, const int* ksta
 // sampling mode of the generation this host thread is running (mode 0 = greedy)
 static thread_local idxtts_sampling samp{0, 1.0f, 0, 1.0f, nullptr, 0};
 thread_local const BeamState* tl_beam = nullptr;
-static thread_local int tl_prof_pos = 0;
+thread_local int tl_prof_pos = 0;
 static thread_local const long long* tl_forced = nullptr;      // teacher-forced generation in flight: [B][max_new] tokens fed back instead of the argmax
 static thread_local int tl_forced_ld = 0;      // keys the eager decode step in flight reads (0 while a captured graph replays)
 

@@ -164,7 +164,12 @@ int GPTModel::generate_beam(const float* inputs_embeds, const int* pad_left_host
   int steps_done = std::min(n_first, max_new);
   for (int n = n_first; n < max_new; ++n) {
     if (gg.exec) IDX_HIP(hipGraphLaunch(gg.exec, st));
-    else if (decode_step(w, R, penalty, nullptr, max_new, nullptr, st)) return 1;
+    else {
+      tl_prof_pos = S + n;      // keys this step reads (profiler accounting of the decode attention)
+      const int rc = decode_step(w, R, penalty, nullptr, max_new, nullptr, st);
+      tl_prof_pos = 0;
+      if (rc) return 1;
+    }
     steps_done = n + 1;
     if ((n & 7) == 7 || n + 1 == max_new) {     // beam_scorer.is_done (every utterance finished)?
       IDX_HIP(hipMemcpyAsync(done.data(), bb.done, B * sizeof(int), hipMemcpyDeviceToHost, st));

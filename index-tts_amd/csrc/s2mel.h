@@ -57,8 +57,9 @@ struct S2MelModel : ModelBase {
                    int Tg, float* cond_out, void* ws, size_t ws_bytes, hipStream_t st);
 };
 
-// the two CFG halves of the solver on two streams (s2mel.hip, dit_eval_halves); default on
+// the two CFG halves of the solver on two streams (s2mel.hip, dit_eval_halves); default OFF (include/idxtts.h::idxtts_s2mel_set_overlap)
 void set_s2mel_overlap(int on);
 int get_s2mel_overlap();
+int s2mel_release_stream(hipStream_t st);      // idxtts_release_stream
 
 }  // namespace idxtts

@@ -580,6 +580,24 @@ static int half_streams_for(hipStream_t st, HalfStreams* out) {
   return 0;
 }
 
+int s2mel_release_stream(hipStream_t st) {      // idxtts_release_stream: the side stream + events kept for a caller stream
+  int dev = 0;
+  IDX_HIP(hipGetDevice(&dev));
+  HalfStreams hs;
+  {
+    std::lock_guard<std::mutex> lk(g_half_mu);
+    auto it = g_half_streams.find(std::make_pair(dev, st));
+    if (it == g_half_streams.end()) return 0;
+    hs = it->second;
+    g_half_streams.erase(it);
+  }
+  if (hs.side) { (void)hipStreamSynchronize(hs.side); (void)hipStreamDestroy(hs.side); }
+  if (hs.fork) (void)hipEventDestroy(hs.fork);
+  if (hs.lag) (void)hipEventDestroy(hs.lag);
+  if (hs.join) (void)hipEventDestroy(hs.join);
+  return 0;
+}
+
 // true: the two halves run as two chains on two streams (half_view buffers); false: ONE stacked evaluation of 2B sequences on the
 // caller's stream (larger launches: 394 instead of 2 x 198 tiles for an N = 512 GEMM fill the second round of CUs better)
 static bool halves_on_two_streams(hipStream_t st) {

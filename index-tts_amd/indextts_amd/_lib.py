@@ -20,7 +20,7 @@ SYMBOLS = [
     "idxtts_fp8_e4m3_decode", "idxtts_fp8_e4m3_encode",
     "idxtts_bigvgan_create", "idxtts_bigvgan_workspace_bytes", "idxtts_bigvgan_fwd", "idxtts_bigvgan_fwd_ragged",
     "idxtts_profile_enable", "idxtts_profile_num_kernels", "idxtts_profile_kernel_name", "idxtts_profile_read", "idxtts_profile_event_overhead",
-    "idxtts_linear_create", "idxtts_linear_fwd", "idxtts_linear_destroy", "idxtts_attention_fwd", "idxtts_attention_bf16x3_fwd", "idxtts_layernorm_fwd",
+    "idxtts_linear_create", "idxtts_linear_fwd", "idxtts_linear_destroy", "idxtts_release_stream", "idxtts_attention_fwd", "idxtts_attention_bf16x3_fwd", "idxtts_layernorm_fwd",
     "idxtts_gpt_create", "idxtts_gpt_quantize_weights", "idxtts_gpt_set_kv_format", "idxtts_gpt_get_kv_format", "idxtts_gpt_workspace_bytes", "idxtts_gpt_embed", "idxtts_gpt_generate", "idxtts_gpt_generate_forced", "idxtts_gpt_generate_sampled", "idxtts_gpt_latent",
     "idxtts_gpt_beam_workspace_bytes", "idxtts_gpt_generate_beam",
     "idxtts_s2mel_create", "idxtts_s2mel_cond_workspace_bytes", "idxtts_s2mel_prepare_cond",
@@ -319,6 +319,11 @@ def set_decode_geometry(narrow: bool) -> None:
 
 def get_decode_geometry() -> bool:
     return bool(load().idxtts_get_decode_geometry())
+
+
+def release_stream(stream) -> None:
+    """Hand a torch.cuda.Stream that is being retired back to the library (per-stream scratch and side streams; include/idxtts.h)."""
+    check(load().idxtts_release_stream(c_void_p(int(stream.cuda_stream))))
 
 
 def set_decode_plane_rows(min_rows: int) -> None:

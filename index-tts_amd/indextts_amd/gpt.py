@@ -83,6 +83,7 @@ class UnifiedVoice:
         self._ws = None
         self._ws_lock = threading.Lock()
         self._conds_cache = {}
+        self._conds_lock = threading.Lock()
         self.stop_mel_token = cfg.stop_mel_token
         self.start_mel_token = cfg.start_mel_token
         self.accel_engine = self       # the reference selects `self.accel_engine.generate` (model_v2.py:871)
@@ -163,18 +164,24 @@ class UnifiedVoice:
         # One prompt is decoded many times (segments, batches, serving lanes): the sum is kept per (latent, emotion vector) storage so that
         # no torch elementwise kernel runs on a decode lane's stream per call (torch's own fp32 kernels beside bf16 MFMAs are
         # outside the NOPK build switch); a consumer on another stream waits for the event of the stream that produced the entry.
+        # (keyed on storage address + torch's version counter: a write that bypasses the counter -- `.data.copy_`, a kernel or collective
+        #  writing through the raw pointer -- is not seen; prompt conditioning tensors are built once and not written again)
         key = (lat.data_ptr(), lat._version, tuple(lat.shape), tuple(lat.stride()), ev.data_ptr(), ev._version, tuple(ev.shape), tuple(ev.stride()))
-        hit = self._conds_cache.get(key)
+        cur = torch.cuda.current_stream(self.device)
+        with self._conds_lock:      # decode lanes call this from several host threads
+            hit = self._conds_cache.get(key)
         if hit is not None:
-            torch.cuda.current_stream(self.device).wait_event(hit[1])
+            cur.wait_event(hit[1])
+            hit[0].record_stream(cur)      # allocated on the producer's stream, read on this one: not reused while a lane still reads it
             return hit[0]
         se = self.speed_emb
         conds = torch.cat([lat + ev[:, None, :], se[1].expand(B, 1, -1), se[0].expand(B, 1, -1)], dim=1).contiguous()
         done = torch.cuda.Event()
-        done.record(torch.cuda.current_stream(self.device))
-        if len(self._conds_cache) >= 16:
-            self._conds_cache.pop(next(iter(self._conds_cache)))
-        self._conds_cache[key] = (conds, done, lat.untyped_storage(), ev.untyped_storage())      # the storages are kept alive: a data_ptr is not reused
+        done.record(cur)
+        with self._conds_lock:
+            if len(self._conds_cache) >= 16:
+                self._conds_cache.pop(next(iter(self._conds_cache)), None)
+            self._conds_cache[key] = (conds, done, lat.untyped_storage(), ev.untyped_storage())      # the storages are kept alive: a data_ptr is not reused
         return conds
 
     def prepare_gpt_inputs(self, conditional_latents: torch.Tensor, text_inputs: torch.Tensor):

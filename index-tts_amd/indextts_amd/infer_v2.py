@@ -377,18 +377,23 @@ class IndexTTS2:
             # file path, as the reference takes it (infer_v2.py:628-630, 685): read, cut to 15 s, resample on the host
             # (indextts_amd/audioio.py); loaded once per path like cache_spk_audio_prompt / cache_emo_audio_prompt (618, 681)
             from .audioio import load_prompt_audio
+            # ONE entry per kind, like the reference's cache_spk_audio_prompt / cache_emo_audio_prompt (infer_v2.py:304-310, 618, 681):
+            # another path replaces it, and so does the same path once the file has changed (size / modification time)
             files = getattr(self, "_prompt_files", None)
             if files is None:
                 files = self._prompt_files = {}
-            skey = ("spk", _os.fspath(spk_audio_prompt))
-            if skey not in files:
-                files[skey] = load_prompt_audio(skey[1])
-            spk_audio_prompt = files[skey]
+
+            def cached(kind, path, **kw):
+                path = _os.fspath(path)
+                st = _os.stat(path)
+                key = (path, st.st_mtime_ns, st.st_size)
+                hit = files.get(kind)
+                if hit is None or hit[0] != key:
+                    hit = files[kind] = (key, load_prompt_audio(path, **kw))
+                return hit[1]
+            spk_audio_prompt = cached("spk", spk_audio_prompt)
             if isinstance(emo_audio_prompt, (str, _os.PathLike)):
-                ekey = ("emo", _os.fspath(emo_audio_prompt))
-                if ekey not in files:
-                    files[ekey] = load_prompt_audio(ekey[1], emotion=True)
-                emo_audio_prompt = files[ekey]
+                emo_audio_prompt = cached("emo", emo_audio_prompt, emotion=True)
         if isinstance(spk_audio_prompt, PromptAudio):
             # audio path: w2v-bert / semantic codec / CAMPPlus / mel / length regulator on the GPU (indextts_amd/prompt.py), cached per
             # prompt object like the reference's cache_spk_cond / cache_emo_cond (infer_v2.py:618, 681)

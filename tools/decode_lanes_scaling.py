@@ -16,8 +16,11 @@ wv = weights.synth_bigvgan_weights(cfg.bigvgan, tag="bench/bigvgan")
 tts = IndexTTS2.from_state_dicts(cfg, wg, ws, wv, device=dev, gpt_weight_format=sys.argv[1] if len(sys.argv) > 1 else "bf16")
 tts.gpt.MAX_WORKSPACES = 16
 cond = PromptConditioning.synthetic(cfg, prompt_frames=689, tag="bench/prompt").to(dev)
-B, L, M = 16, 128, 512
-text = torch.from_numpy(synth.integers("bench/text/rank0", (B, L), 2, cfg.gpt.number_text_tokens))
+B, L, M = (int(sys.argv[2]) if len(sys.argv) > 2 else 16), 128, 512
+from indextts_amd import _lib
+if len(sys.argv) > 3:
+    _lib.set_decode_plane_rows(int(sys.argv[3]))
+text = torch.from_numpy(synth.integers("bench/text/rank0", (64, L), 2, cfg.gpt.number_text_tokens))[:B]
 import warnings; warnings.simplefilter("ignore")
 tls = threading.local()
 def job(k):
@@ -28,7 +31,7 @@ def job(k):
         st = tts.gpt_stage(text, cond, max_mel_tokens=M)
         tls.s.synchronize()
     return st
-for n in (1, 2, 3, 4, 6):
+for n in ((1, 2, 3, 4, 6, 8, 12) if B <= 16 else (1, 2, 3, 4)):
     with concurrent.futures.ThreadPoolExecutor(n) as pool:
         list(pool.map(job, range(n)))          # warm the lanes (workspaces, streams)
         torch.cuda.synchronize()
@@ -36,4 +39,4 @@ for n in (1, 2, 3, 4, 6):
         list(pool.map(job, range(n)))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    print(f"{n:2d} chains together: {dt:.3f} s = {dt / n:.3f} s per batch", flush=True)
+    print(f"{n:2d} chains of {B} rows together: {dt:.3f} s = {dt / n * 16 / B:.3f} s per 16 utterances", flush=True)

@@ -1,5 +1,5 @@
 // Cold-weight timing of the decode GEMV shapes (GPT-2 d = 1280) with ablation masks.  Build on the GPU box:
-//   hipcc -O3 --offload-arch=gfx950 -Iindex-tts_amd/csrc tools/gemv_probe.hip index-tts_amd/csrc/gemv_fx.hip index-tts_amd/csrc/prof.hip -o /tmp/gemv_probe
+//   hipcc -O3 --offload-arch=gfx950 -DGEMV_PROBE -Iindex-tts_amd/csrc tools/gemv_probe.hip index-tts_amd/csrc/gemv_fx.hip index-tts_amd/csrc/prof.hip -o /tmp/gemv_probe
 #include <cstdio>
 #include <vector>
 #include "gemv16.h"
