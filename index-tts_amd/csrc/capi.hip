@@ -334,6 +334,8 @@ int idxtts_gpt_set_kv_format(idxtts_ctx* ctx, int format) {
   IDX_CHECK(format == 0 || format == 1, "KV cache format: 0 (fp32) or 1 (bf16)");
   auto* m = dynamic_cast<GPTModel*>(ctx->model.get());
   IDX_CHECK(m, "not a GPT context");
+  // a generation in flight has carved its workspace for the current format: switching under it would overrun the cache
+  IDX_CHECK(m->kv_fmt == format || m->generating.load() == 0, "a generation is in flight on this context: switch the KV format between generations");
   m->kv_fmt = format;      // cached decode graphs carry the format in their key; workspace sizes follow idxtts_gpt_workspace_bytes
   return 0;
   API_END

@@ -514,18 +514,21 @@ void set_decode_geometry(int narrow) { g_decode_narrow.store(narrow ? 1 : 0); }
 int get_decode_geometry() { return g_decode_narrow.load(); }
 static bool gemv_fx_narrow() { return g_decode_narrow.load() != 0; }
 
-void gemv_fx_plan(int N, int K, int rows, int* ntw, int* kw) {
+static void gemv_fx_plan_geom(int N, int K, int rows, bool narrow_geom, int* ntw, int* kw) {
   const int kc16 = cdiv(K, 16), ntiles = cdiv(N, 16), MT = cdiv(rows, 16);
   int k = 16;
   while (k > 1 && kc16 < k) k >>= 1;
   *kw = k;
-  if (gemv_fx_narrow() && MT == 1 && rows > 4 && kc16 % 80 == 0) { *kw = 8; *ntw = 1; return; }
+  if (narrow_geom && MT == 1 && rows > 4 && kc16 % 80 == 0) { *kw = 8; *ntw = 1; return; }
   // Two column tiles per wave (one activation fragment feeds both) exactly when that turns a two-round launch into one
   // round of <= 256 workgroups (c_fc: 320 tiles); measured per shape in profiles/r01_gemv_probe.txt
   *ntw = (MT <= 2 && ntiles > 256 && cdiv(ntiles, 2) <= 256) ? 2 : 1;
 }
 
+void gemv_fx_plan(int N, int K, int rows, int* ntw, int* kw) { gemv_fx_plan_geom(N, K, rows, gemv_fx_narrow(), ntw, kw); }
+
 int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t stream) {
+  const bool narrow_geom = gemv_fx_narrow();      // the process-wide switch, read ONCE per launch (a setter racing with a launch cannot tear the plan)
   IDX_CHECK(w.wp && a.xf && a.y, "null pointer");
   IDX_CHECK(a.rows > 0 && a.rows <= 64, "1..64 rows");
   IDX_CHECK((reinterpret_cast<uintptr_t>(a.xf) & 15) == 0, "x alignment");
@@ -537,7 +540,7 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
   p.res = a.res; p.y = a.y; p.y_frag = a.y_frag; p.ldy = a.ldy;
   p.rows = a.rows; p.N = w.N; p.K = w.K; p.kc16 = cdiv(w.K, 16); p.ntiles = cdiv(w.N, 16);
   int ntw = 1;
-  gemv_fx_plan(w.N, w.K, a.rows, &ntw, &p.kw);
+  gemv_fx_plan_geom(w.N, w.K, a.rows, narrow_geom, &ntw, &p.kw);
   p.ksb = a.ksb > 1 ? a.ksb : 1;
   p.slab = a.slab; p.cnt = p.ksb > 1 ? a.ksb_counters : nullptr;
   if (p.ksb > 1 && !p.cnt) IDX_CHECK(!a.colsum && !a.bias && !a.res && a.act == 0 && !a.y_frag, "a K-split launch writes raw partial sums");
@@ -545,8 +548,8 @@ int gemv_fx_forward(const Gemv16Weights& w, const GemvFXArgs& a, hipStream_t str
   p.cps = cdiv(p.kc16, p.kw * p.ksb);
   p.act = a.act; p.dbg = a.dbg;
   const int MT = cdiv(a.rows, 16);
-  const bool narrow = p.kw == 8 && p.cps == 10 && MT == 1 && a.rows > 4 && w.fmt != WFMT_F32 && gemv_fx_narrow();
-  if (p.kw == 8 && !narrow && gemv_fx_narrow() && MT == 1 && a.rows > 4 && cdiv(w.K, 16) % 80 == 0) {      // fp32 streams: the 16-wave form
+  const bool narrow = p.kw == 8 && p.cps == 10 && MT == 1 && a.rows > 4 && w.fmt != WFMT_F32 && narrow_geom;
+  if (p.kw == 8 && !narrow && narrow_geom && MT == 1 && a.rows > 4 && cdiv(w.K, 16) % 80 == 0) {      // fp32 streams: the 16-wave form
     p.kw = 16; p.cps = cdiv(p.kc16, p.kw * p.ksb);
     ntw = (p.ntiles > 256 && cdiv(p.ntiles, 2) <= 256) ? 2 : 1;
   }

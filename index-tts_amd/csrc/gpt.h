@@ -35,6 +35,8 @@ struct GPTModel : ModelBase {
   const float *mel_emb = nullptr, *text_emb = nullptr, *mel_pos = nullptr, *text_pos = nullptr;
   int weight_fmt = WFMT_F32;      // storage format of the decode weight streams (quantize_weights)
   int kv_fmt = 0;                 // KV cache of the cached generation: 0 = fp32, 1 = bf16 (keys / values rounded when produced; decode.h)
+  std::atomic<int> generating{0}; // generate() / generate_beam() calls in flight: idxtts_gpt_set_kv_format refuses to switch under them
+  struct GenScope { GPTModel* m; explicit GenScope(GPTModel* mm) : m(mm) { m->generating.fetch_add(1); } ~GenScope() { m->generating.fetch_sub(1); } };
   size_t kv_layer_bytes(int B, int Smax) const { return (size_t)B * cfg.heads * Smax * 64 * (kv_fmt ? 2 : 4); }
   hipStream_t own_stream = nullptr;
   static constexpr int OOB_SLOTS = 64;

@@ -464,6 +464,7 @@ int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int
                        const idxtts_sampling* sampling, long long* codes, int* n_steps_out, float* logits_out, void* ws, size_t ws_bytes, int use_graph,
                        hipStream_t user_stream, const long long* forced) {
   IDX_CHECK(inputs_embeds && codes && n_steps_out, "null pointer");
+  GenScope gen_scope(this);
   struct ForcedScope {      // the forced tokens apply to this call only, whatever path it returns on
     ForcedScope(const long long* f, int ld) { tl_forced = f; tl_forced_ld = ld; }
     ~ForcedScope() { tl_forced = nullptr; tl_forced_ld = 0; }

@@ -62,6 +62,7 @@ int GPTModel::generate_beam(const float* inputs_embeds, const int* pad_left_host
                             const idxtts_beam* beam, long long* codes, int* n_steps_out, void* ws, size_t ws_bytes, int use_graph,
                             hipStream_t user_stream) {
   IDX_CHECK(inputs_embeds && codes && n_steps_out && beam, "null pointer");
+  GenScope gen_scope(this);
   hipStream_t st = user_stream;
   if (user_stream == nullptr) {
     if (!own_stream) IDX_HIP(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
