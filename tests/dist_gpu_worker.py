@@ -1,7 +1,7 @@
 """Worker of tests/test_dist_gpu.py: one rank of a two-rank job on ONE GPU (gloo for the collectives, both ranks on cuda:0).
 The product-level sharded call -- ShardedSynthesizer over the real HIP pipeline, each rank with its own BatchPipeline -- on an
 uneven utterance list of ragged texts; rank 0 compares the gathered waveforms, in the caller's order, with its own single-process
-synthesis of every utterance."""
+synthesis of the same batches."""
 import os
 import sys
 import warnings
@@ -46,10 +46,25 @@ def main() -> int:
     ok = True
     if rank == 0:
         assert got is not None and len(got) == n
+        # the single-process result: the same batches (sorted by length, contiguous shards, batches of BS, padded with the stop token --
+        # what ShardedSynthesizer documents), one after the other on this rank
+        from indextts_amd.dist import shard_bounds, sort_by_length
         stop = cfg.gpt.stop_text_token
-        for i in range(n):       # the single-process call of utterance i alone (rows of a batch do not depend on their neighbours)
-            want = tts.synthesize_batch(torch.tensor([texts[i]], dtype=torch.long), cond.to(dev), max_mel_tokens=M, noise=noise_all[i:i + 1])[0]
-            same = got[i].shape == want.shape and torch.equal(got[i].to(dev), want)
+        order = sort_by_length(lens)
+        want = [None] * n
+        for r in range(world):
+            lo, hi = shard_bounds(n, world, r)
+            mine = order[lo:hi]
+            for b0 in range(0, len(mine), BS):
+                idx = mine[b0:b0 + BS]
+                L = max(lens[i] for i in idx)
+                toks = torch.full((len(idx), L), stop, dtype=torch.long)
+                for row, i in enumerate(idx):
+                    toks[row, : lens[i]] = torch.tensor(texts[i], dtype=torch.long)
+                for i, w in zip(idx, tts.synthesize_batch(toks, cond.to(dev), max_mel_tokens=M, noise=noise_all[idx])):
+                    want[i] = w
+        for i in range(n):
+            same = got[i].shape == want[i].shape and torch.equal(got[i].to(dev), want[i])
             if not same:
                 print(f"utterance {i}: sharded result differs from the single-process call", flush=True)
             ok = ok and same

