@@ -138,9 +138,16 @@ def stage_rooflines(stages, prof, nprof, B, L, M, Tp, Tg, n_cfm, w_bytes_per_par
     t = stages.get("gpt_gen_time")
     if t:
         dec_launches = sum(v["launches"] for k, v in prof.items() if k.startswith(DECODE_KERNELS)) / max(nprof, 1)
+        # The floor of one decode chain: its bytes at the ACHIEVABLE HBM rate (6.3 TB/s, MI355X_MICROARCH.md) plus one dependent kernel
+        # boundary per launch (1.45 us between trivial kernels, 1.7-1.9 between streaming ones: the guide's price list) -- the launches of a
+        # token form a dependency chain, so the boundaries do not overlap with anything of the same chain.
+        lpt = dec_launches / M
+        floor_us = 1e6 * (dec_bytes / M) / 6.3e12 + lpt * 1.5
         out["gpt_decode"] = {"bound": "hbm", "alg_bytes_per_step": dec_bytes, "seconds": t, "achieved": round(dec_bytes / t / 1e9, 1), "peak": PEAK_HBM_GBS,
-                             "unit": "GB/s", "frac": round(dec_bytes / t / 1e9 / PEAK_HBM_GBS, 4), "launches_per_token": round(dec_launches / M, 1),
-                             "us_per_token": round(1e6 * t / M, 1), "kv_cache": "bf16" if kv_bytes == 2 else "fp32", "note": "gpt_gen_time includes the prefill (165 tokens, MFMA)"}
+                             "unit": "GB/s", "frac": round(dec_bytes / t / 1e9 / PEAK_HBM_GBS, 4), "launches_per_token": round(lpt, 1),
+                             "us_per_token": round(1e6 * t / M, 1), "floor_us_per_token": round(floor_us, 1), "times_the_floor": round(1e6 * t / M / floor_us, 2),
+                             "floor_note": "bytes per token / 6.3 TB/s (achievable HBM rate) + launches per token x 1.5 us (dependent kernel boundary)",
+                             "kv_cache": "bf16" if kv_bytes == 2 else "fp32", "note": "gpt_gen_time includes the prefill (165 tokens, MFMA)"}
     T = Tp + Tg
     s2_flops = n_cfm * 2 * B * T * (148.4e6 + 26624.0 * T)
     t = stages.get("s2mel_time")
@@ -750,6 +757,8 @@ def main() -> int:
             ntok = cfgd["batch_per_gpu"] * cfgd["codes"]
             res["decode"] = {"tokens_per_s": round(ntok / stages["gpt_gen_time"], 1), "ms_per_token_step": round(1000 * stages["gpt_gen_time"] / cfgd["codes"], 4),
                              "note": "gpt_gen_time includes the prefill; one step = one token for every utterance of the batch"}
+            if roofline_stages and "gpt_decode" in roofline_stages:
+                res["decode"].update({k: roofline_stages["gpt_decode"][k] for k in ("launches_per_token", "us_per_token", "floor_us_per_token", "times_the_floor")})
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -70,6 +70,11 @@ def test_encode_stage_by_stage_vs_oracles(device, rig):
         ne = int(fe["attention_mask"].sum())
         emo = osem.get_emb(tw(ww), wcfg, torch.from_numpy(fe["input_features"]), torch.from_numpy(fe["attention_mask"]))[:, :ne]
         assert (got.emo_cond_emb.cpu() - emo).abs().max().item() <= 2e-4
+        # the two prompts went through w2v-bert as ONE ragged batch: each row is its own B = 1 call (at this toy size the batch has 260
+        # GEMM rows and a prompt alone 130: the batch is on the split-bf16 GEMM, the single call below 256 rows on the exact one --
+        # a real prompt of more than 5 s is on the split-bf16 kernel either way)
+        for one, solo in ((got.spk_cond_emb, enc.get_emb(a16)), (got.emo_cond_emb, enc.get_emb(_audio("t/prompt/e16", 16000, 1.7)))):
+            assert one.shape == solo.shape and (one - solo).abs().max().item() <= 2e-4
         # the next stage's oracle gets THIS path's features, so a near-tie of the nearest-code search upstream cannot cascade
         _, S_ref = ocd.quantize(tw(wc), got.spk_cond_emb.cpu())
         mel = oa.mel_spectrogram(torch.from_numpy(a22[None]), torch.from_numpy(slaney_mel_basis(22050, 1024, cfg.s2mel.in_channels)))
