@@ -87,14 +87,16 @@ def roofline_from_profile(prof, steps, workload="pipeline", split_bf16=True, def
              "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None, "alg_bytes_per_launch": dom["bytes"] / dom["launches"]}
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (separate --pmc FETCH_SIZE /
     # WRITE_SIZE runs, gfx950 correction applied; profiles/README.md) -- null when no pass is on file for this kernel
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic_r03.json")) as f:
-            tr = json.load(f)["kernels"].get(dom_name)
-        if tr and workload == "pipeline" and default_config:      # the PMC passes on file are of the default configs[2] command
-            r["traffic"] = tr["hbm_bytes_per_launch"]
-            r["traffic_source"] = "profiles/traffic_r03.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes = (2*FETCH+WRITE)*1024)"
-    except (OSError, KeyError, ValueError):
-        pass
+    for rnd in ("r04", "r03"):      # the newest PMC passes on file
+        try:
+            with open(os.path.join(ROOT, "profiles", f"traffic_{rnd}.json")) as f:
+                tr = json.load(f)["kernels"].get(dom_name)
+            if tr and workload == "pipeline" and default_config:      # the PMC passes on file are of the default configs[2] command
+                r["traffic"] = tr["hbm_bytes_per_launch"]
+                r["traffic_source"] = f"profiles/traffic_{rnd}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes = (2*FETCH+WRITE)*1024)"
+                break
+        except (OSError, KeyError, ValueError):
+            pass
     r["launches_per_step"] = dom["launches"] // steps
     r["avg_launch_ms"] = round(dom_ms / dom["launches"], 5)
     r["avg_launch_ms_raw"] = round(dom["ms"] / dom["launches"], 5)
@@ -319,6 +321,8 @@ def build_pipeline(args, world, rank, dev):
         ctext = text[:1, :Lc].clone()
         Tgc = int(Mc * cfg.code_to_frame)
         cnoise = noise[:1, :, : Tp + Tgc].cpu()
+        if cnoise.shape[-1] < Tp + Tgc:      # the bounded sample is longer than the run's utterances (--cpu-codes > --codes): its own draw
+            cnoise = torch.from_numpy(synth.uniform("bench/noise/cpu-leg", (1, cfg.s2mel.in_channels, Tp + Tgc), 1.7))
         twg = {k: torch.from_numpy(v) for k, v in wg.items()}
         tws = {k: torch.from_numpy(v) for k, v in ws.items()}
         log(f"[bench] cpu baseline: oracle pipeline, 1 utterance, {Lc} text tokens, {Mc} codes, Tp={Tp}, "

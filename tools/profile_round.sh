@@ -19,13 +19,23 @@ cd /tmp && export TMPDIR=/tmp
 HB=$!
 trap "kill $HB 2>/dev/null" EXIT
 ACOUSTIC='gemm_bf16x3|conv1d_|flash_attn|aa_act|ada_rms|rows_norm|split_planes|gemm_tn|conv_post|cfm_'
-DECODE='gemv_fx|decode_attn|sample_greedy|embed_step'
+DECODE='gemv_fx|gemv_pl|decode_attn|sample_greedy|embed_step'
 if [ "$WHAT" = all ] || [ "$WHAT" = stats ]; then
   rm -rf /tmp/prof_ks
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-overlap --decode-geometry narrow > $OUT/${R}_prof_ks.log 2>&1 || exit 1
   cp $(find /tmp/prof_ks -name "*kernel_stats.csv" | head -1) $OUT/${R}_pipeline_kernel_stats.csv
   rm -rf /tmp/prof_ks
   echo "kernel stats done"
+  # the PIPELINED run itself (what the driver's line times: three decode lanes beside the acoustic stage; kernel durations include the
+  # contention), and the merged-decode variant (three 16-utterance requests decoded as ONE 48-row batch on the plane GEMV)
+  rm -rf /tmp/prof_kp
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kp -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-exact-mode > $OUT/${R}_prof_kp.log 2>&1 || exit 1
+  cp $(find /tmp/prof_kp -name "*kernel_stats.csv" | head -1) $OUT/${R}_pipeline_pipelined_kernel_stats.csv
+  rm -rf /tmp/prof_kp
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kp -- python3 $ROOT/bench.py --steps 9 --warmup 3 --no-cpu-baseline --no-roofline --no-exact-mode --coalesce 3 --decode-lanes 2 > $OUT/${R}_prof_kc.log 2>&1 || exit 1
+  cp $(find /tmp/prof_kp -name "*kernel_stats.csv" | head -1) $OUT/${R}_pipeline_coalesced_kernel_stats.csv
+  rm -rf /tmp/prof_kp
+  echo "pipelined + coalesced kernel stats done"
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = pmc ]; then
   for C in FETCH_SIZE WRITE_SIZE; do
