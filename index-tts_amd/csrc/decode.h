@@ -47,12 +47,13 @@ struct SampleArgs {
   // teacher forcing (idxtts_gpt_generate_forced): `codes` still records the row's own argmax, but the token fed back (cur_tok, the
   // repetition-penalty set, the finished flag) is forced[b][step]
   const long long* forced = nullptr; int forced_ld = 0;
-  // Fused tail of a greedy step on the plane-GEMV path (embed.x_row != null): the workgroup that picked row b's token also writes the NEXT
+  // Fused tail of a greedy step (embed.x_row or embed.x_frag != null): the workgroup that picked row b's token also writes the NEXT
   // step's input x[b] = mel_emb[token] + mel_pos[st->mel_pos + 1] (model_v2.py:173-177) -- as the fp32 residual row
   // and the per-16-column row statistics of the first folded LayerNorm -- and the last workgroup to arrive advances the
   // step scalars (DecodeState::arrive counts them): sample + embed + advance in ONE launch.
   struct Embed {
-    float* x_row = nullptr; float* x_stats = nullptr;
+    float* x_row = nullptr; float* x_stats = nullptr;      // plane-GEMV step: fp32 row + per-16-column statistics, or
+    float* x_frag = nullptr;                               // fp32-MFMA GEMV step: the A-fragment image (frag_index)
     const float* mel_emb = nullptr; const float* mel_pos = nullptr; int d = 0;
     DecodeState* st_rw = nullptr;
   } embed;

@@ -464,7 +464,8 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs p)
   __shared__ float rv[16];
   __shared__ int ri[16];
   __shared__ int s_tok;
-  const int mp_next = p.embed.x_row ? p.st->mel_pos + 1 : 0;      // read before anybody can advance the state
+  const bool fused = p.embed.x_row || p.embed.x_frag;
+  const int mp_next = fused ? p.st->mel_pos + 1 : 0;      // read before anybody can advance the state
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int V = p.V;
   float best = -INFINITY;
@@ -516,9 +517,14 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs p)
     p.cur_tok[b] = tok;
     s_tok = tok;
   }
-  if (!p.embed.x_row) return;
+  if (!fused) return;
   __syncthreads();
-  embed_row_pl<1024>(p.embed.x_row, p.embed.x_stats, b, p.B, p.embed.d, p.embed.mel_emb, p.embed.mel_pos, s_tok, mp_next, tid);
+  if (p.embed.x_frag) {      // fp32-MFMA GEMV step: x as A-fragment images (the folded LayerNorm's statistics are computed by the consumer)
+    const int d = p.embed.d, tok = s_tok;
+    for (int e = tid; e < d; e += 1024) p.embed.x_frag[frag_index(b, e, d >> 4)] = p.embed.mel_emb[(size_t)tok * d + e] + p.embed.mel_pos[(size_t)mp_next * d + e];
+  } else {
+    embed_row_pl<1024>(p.embed.x_row, p.embed.x_stats, b, p.B, p.embed.d, p.embed.mel_emb, p.embed.mel_pos, s_tok, mp_next, tid);
+  }
   __syncthreads();      // every read of the step scalars by this workgroup is behind us
   if (tid == 0) {
     DecodeState* st = p.embed.st_rw;

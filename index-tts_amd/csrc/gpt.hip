@@ -12,7 +12,7 @@
 //   c_attn [LayerNorm 1 folded in] -> decode_attn (+ KV-cache write) -> c_proj (+ residual, in place)
 //   -> c_fc [LayerNorm 2 folded in, gelu_new] -> mlp.c_proj (+ residual; K split over 4 workgroups per column tile, finished
 //   by the last one to arrive),
-// + embedding, final norms, head and sampler: 125 launches per token.  Every per-step scalar is device-resident, so the whole
+// + final norms, head and ONE launch for sampler + next embedding + advance (greedy): 123 launches per token.  Every per-step scalar is device-resident, so the whole
 // step is captured once into a hipGraph and replayed per token (launch-bound otherwise).
 // The decode weight streams are fp32 by default; quantize_weights() rounds the model once to bf16 / fp8-e4m3 storage
 // (BASELINE configs[4]) -- the arithmetic stays the fp32 MFMA.
@@ -360,8 +360,8 @@ int GPTModel::head_and_sample(const Buffers& w, int B, const float* x, int ldx, 
   s.st = w.state; s.B = B; s.V = V; s.stop_token = cfg.stop_mel_token; s.penalty = penalty;
   s.forced = tl_forced; s.forced_ld = tl_forced_ld;
   if (fused_tail(B)) {      // the sampler's workgroups also write the next step's input and advance the step scalars
-    s.embed.x_row = w.xrow; s.embed.x_stats = w.stats; s.embed.mel_emb = mel_emb; s.embed.mel_pos = mel_pos; s.embed.d = d;
-    s.embed.st_rw = w.state;
+    if (pl) { s.embed.x_row = w.xrow; s.embed.x_stats = w.stats; } else s.embed.x_frag = w.xd;
+    s.embed.mel_emb = mel_emb; s.embed.mel_pos = mel_pos; s.embed.d = d; s.embed.st_rw = w.state;
   }
   if (samp.mode != 0) {
     SampleWarpArgs sw;
@@ -379,7 +379,7 @@ int GPTModel::head_and_sample(const Buffers& w, int B, const float* x, int ldx, 
 // requests, 16 utterances x 3 beams).  Measured on the full-size model, 256 tokens, graph replay: 16 rows 0.328 s against 0.303 s on the
 // fp32-MFMA GEMV (its single-round-trip launches win), 32 rows 0.432 / 0.432, 48 rows 0.567 / 0.612 (profiles/README.md "Round 4").
 bool GPTModel::use_pl(int B) const { return weight_fmt != WFMT_F32 && B >= get_decode_plane_rows() && cfg.model_dim % 32 == 0 && head_p.wp; }
-bool GPTModel::fused_tail(int B) const { return use_pl(B) && samp.mode == 0 && !tl_beam; }
+bool GPTModel::fused_tail(int B) const { (void)B; return samp.mode == 0 && !tl_beam; }      // greedy: sample + next embedding + advance are ONE launch
 
 // The decode step on the plane GEMV (gemv_pl.hip): the same five launches per layer, every activation a plain fp32 row-major matrix
 // (split into bf16 planes inside the GEMV), the residual stream updated in place, the LayerNorm statistics handed from producer to consumer; greedy generations close the
@@ -424,7 +424,8 @@ int GPTModel::decode_step(const Buffers& w, int B, float penalty, long long* cod
   if (use_pl(B)) return decode_step_pl(w, B, penalty, codes, codes_ld, logits_base, st);
   const int d = cfg.model_dim;
   const size_t per_layer = kv_layer_bytes(B, w.Smax);
-  if (embed_step(w.xd, B, d, mel_emb, mel_pos, w.cur_tok, w.state, st)) return 1;
+  const bool fused = fused_tail(B);      // greedy: the previous step's sampler has written this step's x and advanced the step scalars
+  if (!fused && embed_step(w.xd, B, d, mel_emb, mel_pos, w.cur_tok, w.state, st)) return 1;
   for (int li = 0; li < cfg.layers; ++li) {
     const GPTLayer& L = layers[li];
     GemvFXArgs qa;      // qkv = c_attn(LN1(x)) + b, row-major for the attention kernel
@@ -457,7 +458,7 @@ int GPTModel::decode_step(const Buffers& w, int B, float penalty, long long* cod
     }
   }
   if (head_and_sample(w, B, w.xd, d, true, penalty, codes, codes_ld, logits_base, st)) return 1;
-  return advance_state(w.state, st);
+  return fused ? 0 : advance_state(w.state, st);
 }
 
 int GPTModel::generate(const float* inputs_embeds, const int* pad_left_host, int B, int P, int max_new, float penalty,
