@@ -378,7 +378,7 @@ def build_pipeline(args, world, rank, dev):
                                       and pr["first_difference_step_free_running"] == pr["first_mismatch_step_teacher_forced"])
             par[mode] = pr
             log(f"[bench] decode parity, KV {mode}: {PB} utterances x {pr['steps']} steps teacher-forced on the oracle's codes: max |dlogit| "
-                f"{pr['max_abs_logit_diff']:.2e} (bound {bound:.0e}, logit std {pr['logit_std']:.2f}), argmax match rate {pr['codes_match_rate_teacher_forced']:.4f}, "
+                f"{pr['max_abs_logit_diff']:.2e} (bound {bound:.1e}, logit std {pr['logit_std']:.2f}), argmax match rate {pr['codes_match_rate_teacher_forced']:.4f}, "
                 f"{len(pr['mismatching_steps'])} differing step(s), worst oracle margin there {pr['worst_oracle_margin_at_a_mismatch']:.2e}; free-running: first "
                 f"difference per utterance {pr['first_difference_step_free_running']}; within bound: {pr['within_bound']}")
         tts.gpt.set_kv_format(own)

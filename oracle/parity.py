@@ -33,9 +33,12 @@ def decode_parity(uv, tw: Dict[str, torch.Tensor], gcfg, spk_latent: torch.Tenso
     path's cache (`kv_round`) when uv.kv_format == "bf16"."""
     kv_round = uv.kv_format == "bf16"
     B = text.shape[0]
+    import time
     with torch.no_grad():
         conds = og.conds_latent(tw, gcfg, spk_latent, emo_vec)
+        t0 = time.perf_counter()
         codes_ref, logits_ref = og.generate_greedy(tw, gcfg, conds, text, n_codes, penalty, return_logits=True, kv_round=kv_round)
+        oracle_s = time.perf_counter() - t0
         fake = og.prepare_gpt_inputs(tw, gcfg, conds, text)[0]
     n = codes_ref.shape[1]
     forced = torch.full((B, n_codes), gcfg.stop_mel_token, dtype=torch.long)
@@ -72,6 +75,7 @@ def decode_parity(uv, tw: Dict[str, torch.Tensor], gcfg, spk_latent: torch.Tenso
                 top2_all.append(float(t2[0] - t2[1]))
     return {
         "utterances": B, "steps": int(n), "kv_cache": uv.kv_format, "gpt_weights": uv.weight_format,
+        "oracle_decode_seconds": round(oracle_s, 2), "oracle_decode_tokens_per_s": round(B * int(n) / oracle_s, 1),
         "max_abs_logit_diff": float(dl.max()), "mean_abs_logit_diff": float(dl.mean()), "logit_std": float(logits_ref[live].std()),
         "logit_entries_compared": "all with |oracle logit| < 1e3 (the -1e4 stop-token bias of fixed-length synthetic utterances is excluded)",
         "codes_match_rate_teacher_forced": float(1.0 - mism.float().mean()),

@@ -13,6 +13,6 @@ for W in prompt infer_default; do
   echo "$W kernel stats done"
 done
 rm -rf /tmp/prof_w
-cp $OUT/traffic_${R}.json $ROOT/profiles/traffic_${R}.json
+[ -f $OUT/traffic_${R}.json ] && cp $OUT/traffic_${R}.json $ROOT/profiles/traffic_${R}.json
 cd $ROOT && python3 bench.py > $OUT/${R}_pipeline_bench.log 2>&1 || exit 1
 tail -1 $OUT/${R}_pipeline_bench.log | cut -c1-300
