@@ -18,8 +18,10 @@ tts.gpt.MAX_WORKSPACES = 16
 cond = PromptConditioning.synthetic(cfg, prompt_frames=689, tag="bench/prompt").to(dev)
 B, L, M = (int(sys.argv[2]) if len(sys.argv) > 2 else 16), 128, 512
 from indextts_amd import _lib
-if len(sys.argv) > 3:
+if len(sys.argv) > 3 and int(sys.argv[3]):
     _lib.set_decode_plane_rows(int(sys.argv[3]))
+if len(sys.argv) > 4 and sys.argv[4] == "narrow":
+    _lib.load(); _lib.set_decode_geometry(True)
 text = torch.from_numpy(synth.integers("bench/text/rank0", (64, L), 2, cfg.gpt.number_text_tokens))[:B]
 import warnings; warnings.simplefilter("ignore")
 tls = threading.local()
