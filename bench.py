@@ -270,7 +270,7 @@ def build_pipeline(args, world, rank, dev):
     lanes = max(1, args.decode_lanes)
     pipe = None if args.no_overlap else BatchPipeline(tts, decode_lanes=lanes, acoustic_workers=max(1, args.acoustic_workers),
                                                       coalesce=max(1, args.coalesce), lane_priority=args.lane_priority,
-                                                      acoustic_coalesce=max(1, args.acoustic_coalesce))
+                                                      acoustic_coalesce=max(1, args.acoustic_coalesce), exclusive=args.exclusive)
     # batches submitted and not yet retired: every lane full plus what one acoustic batch takes
     in_flight = lanes * max(1, args.coalesce) + max(1, args.acoustic_coalesce)
     if pipe is not None and args.trace_jobs:
@@ -408,6 +408,7 @@ def build_pipeline(args, world, rank, dev):
                             + (f", a free lane decodes up to {args.coalesce} waiting 16-utterance requests as one batch" if args.coalesce > 1 else "")
                             + f"), {max(1, args.acoustic_workers)} s2mel+vocoder stage(s) at a time behind them"
                             + (f" (a free one takes up to {args.acoustic_coalesce} decoded requests as one batch)" if args.acoustic_coalesce > 1 else "")
+                            + ("; decode jobs and acoustic jobs take turns on the chip (exclusive)" if args.exclusive else "")
                             + "; every batch inside the timed region")
     step.flush = (lambda: None) if args.no_overlap else flush
     nref = 16 if world > 1 else len(text)        # multi-rank: a shard goes through the pipeline in batches of 16
@@ -531,6 +532,9 @@ def main() -> int:
     ap.add_argument("--acoustic-coalesce", type=int, default=1, help="pipeline workload: a free acoustic worker takes up to this many decoded requests as one s2mel + vocoder batch")
     ap.add_argument("--coalesce", type=int, default=1,
                     help="pipeline workload: a free decode lane takes up to this many waiting 16-utterance requests and decodes them as one batch")
+    ap.add_argument("--exclusive", action="store_true",
+                    help="pipeline workload: a decode job and an acoustic job never share the chip (BatchPipeline(exclusive=True)): the "
+                         "pipeline only merges and re-orders")
     ap.add_argument("--s2mel-overlap", action="store_true",
                     help="the CFM solver's two CFG halves on two streams (idxtts_s2mel_set_overlap): faster alone, slower beside decode lanes")
     ap.add_argument("--trace-jobs", action="store_true", help="pipeline workload: log the host-side start / end of every decode and acoustic job")

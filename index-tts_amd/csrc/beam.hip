@@ -18,6 +18,7 @@ namespace {
 
 constexpr int NPT = 16;          // vocabulary entries per thread of a 1024-thread block: V <= 16384
 constexpr int CAP = 2048;        // survivors of the top-k filter handled by the top-p stage
+constexpr int SEL_EPT = 32;      // beam_select: candidates per thread kept in registers (nb * V <= 32768), else the re-reading loop
 
 __device__ __forceinline__ void block_argmax1024(float& v, int& i, float* rv, int* ri, int tid) {   // max value, smallest index on ties
 #pragma unroll
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(1024) void beam_scores_kernel(const BeamState p) {
   __shared__ int sidx[CAP];
   __shared__ float sorted_v[CAP];
   __shared__ int sorted_i[CAP];
-  __shared__ int s_count, s_thr_i;
+  __shared__ int s_count, s_thr_i, s_digit, s_kk;
+  __shared__ int hist[16][256];
   __shared__ float s_thr_v;
   const int r = blockIdx.x, tid = threadIdx.x, V = p.V;
   if (p.done[r / p.nb]) return;
@@ -88,19 +90,58 @@ __global__ __launch_bounds__(1024) void beam_scores_kernel(const BeamState p) {
   if (p.do_sample && (p.top_k > 0 || p.top_p < 1.0f)) {
     const int k = p.top_k > 0 ? max(p.top_k, 2) : 0;         // TopKLogitsWarper: max(top_k, min_tokens_to_keep)
     if (k > 0 && k < V) {
-      unsigned taken = 0;
-      float kth = -INFINITY;
-      for (int rd = 0; rd < k; ++rd) {
-        float m2 = -INFINITY; int i2 = 0x7fffffff;
+      // the k-th largest score by a radix select over order-preserving 32-bit keys (four 8-bit digits, high to low): per-wave
+      // histograms in LDS, one wave walks the 256 bins from the top -- 16 barriers in all instead of 2 k block-wide argmax rounds
+      unsigned key[NPT];
 #pragma unroll
-        for (int u = 0; u < NPT; ++u) {
-          const int v = tid + 1024 * u;
-          if (v < V && !((taken >> u) & 1u) && (sc[u] > m2 || (sc[u] == m2 && v < i2))) { m2 = sc[u]; i2 = v; }
-        }
-        block_argmax1024(m2, i2, rv, ri, tid);
-        kth = m2;
-        if ((i2 & 1023) == tid && i2 < V) taken |= 1u << (i2 >> 10);
+      for (int u = 0; u < NPT; ++u) {
+        const unsigned b = __float_as_uint(sc[u] + 0.0f);      // (+ 0: -0 and +0 are one value to `<`)
+        key[u] = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
       }
+      unsigned prefix = 0;
+      int kk = k;
+      const int wv = tid >> 6, ln = tid & 63;
+      for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) (&hist[0][0])[tid + 1024 * j] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NPT; ++u)
+          if (tid + 1024 * u < V && (pass == 0 || (key[u] >> (shift + 8)) == prefix)) atomicAdd(&hist[wv][(key[u] >> shift) & 255u], 1);
+        __syncthreads();
+        if (tid < 256) {
+          int t = 0;
+#pragma unroll
+          for (int w = 0; w < 16; ++w) t += hist[w][tid];
+          hist[0][tid] = t;
+        }
+        __syncthreads();
+        if (wv == 0) {      // lane l owns bins 4 l .. 4 l + 3; `above` = the count in every bin of a higher lane
+          int c[4], mine = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { c[j] = hist[0][4 * ln + j]; mine += c[j]; }
+          int incl = mine;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_down(incl, off);
+            if (ln + off < 64) incl += o;
+          }
+          int a = incl - mine;
+          if (a < kk && kk <= incl) {
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+              if (a + c[j] >= kk) { s_digit = 4 * ln + j; s_kk = kk - a; break; }
+              a += c[j];
+            }
+          }
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | (unsigned)s_digit;
+        kk = s_kk;
+      }
+      const unsigned kb = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
+      const float kth = __uint_as_float(kb);
 #pragma unroll
       for (int u = 0; u < NPT; ++u) if (sc[u] < kth) sc[u] = -INFINITY;
     }
@@ -179,31 +220,69 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(const BeamState p) {
   }
   const float* base = p.proc + (size_t)b * N;
   const size_t nbase = ((size_t)n * p.B + b) * N;
-  float mx = -INFINITY; int mi = 0x7fffffff;
-  for (int i = tid; i < N; i += 1024) { const float x = base[i]; if (x > mx || (x == mx && i < mi)) { mx = x; mi = i; } }
-  block_argmax1024(mx, mi, rv, ri, tid);
-  float tot = 1.0f;
-  if (p.do_sample) {
-    float part = 0.f;
-    for (int i = tid; i < N; i += 1024) part += expf(base[i] - mx);
-    tot = block_sum1024(part, rv, tid);
-  }
   const int n_keep = 2 * nb;
   // multinomial without replacement = the n_keep largest probs / q (ATen: q ~ Exp(1) once per element, then topk); plain
   // top-k of the scores when not sampling.  Ties (only among zero-probability fillers) go to the smaller index.
-  for (int c = 0; c < n_keep; ++c) {
-    float best = -INFINITY; int bi = 0x7fffffff;
-    for (int i = tid; i < N; i += 1024) {
-      bool taken = false;
-      for (int o = 0; o < c; ++o) taken = taken || cand_i[o] == i;
-      if (taken) continue;
-      const float x = base[i];
-      const float key = p.do_sample ? (expf(x - mx) / tot) / exp1_draw(p.exp_noise, p.seed, nbase + i) : x;
-      if (key > best || (key == best && i < bi)) { best = key; bi = i; }
+  if (N <= 1024 * SEL_EPT) {
+    // every element's key is computed ONCE and stays in registers (the exponential, the division and the draw are the cost of a
+    // round); a round is then a masked scan of SEL_EPT registers and one block-wide argmax
+    float ks[SEL_EPT];
+    float mx = -INFINITY; int mi = 0x7fffffff;
+#pragma unroll
+    for (int e = 0; e < SEL_EPT; ++e) {
+      const int i = tid + 1024 * e;
+      ks[e] = i < N ? base[i] : -INFINITY;
+      if (i < N && (ks[e] > mx || (ks[e] == mx && i < mi))) { mx = ks[e]; mi = i; }
     }
-    block_argmax1024(best, bi, rv, ri, tid);
-    if (tid == 0) { cand_i[c] = bi; cand_s[c] = base[bi]; }
+    block_argmax1024(mx, mi, rv, ri, tid);
+    if (p.do_sample) {
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < SEL_EPT; ++e) if (tid + 1024 * e < N) part += expf(ks[e] - mx);
+      const float tot = block_sum1024(part, rv, tid);
+#pragma unroll
+      for (int e = 0; e < SEL_EPT; ++e) {
+        const int i = tid + 1024 * e;
+        if (i < N) ks[e] = (expf(ks[e] - mx) / tot) / exp1_draw(p.exp_noise, p.seed, nbase + i);
+      }
+    }
+    unsigned taken = 0;
+    for (int c = 0; c < n_keep; ++c) {
+      float best = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+      for (int e = 0; e < SEL_EPT; ++e) {
+        const int i = tid + 1024 * e;
+        if (i < N && !((taken >> e) & 1u) && (ks[e] > best || (ks[e] == best && i < bi))) { best = ks[e]; bi = i; }
+      }
+      block_argmax1024(best, bi, rv, ri, tid);
+      if (bi < N && (bi & 1023) == tid) taken |= 1u << (bi >> 10);
+      if (tid == 0) { cand_i[c] = bi; cand_s[c] = base[bi]; }
+    }
     __syncthreads();
+  } else {
+    float mx = -INFINITY; int mi = 0x7fffffff;
+    for (int i = tid; i < N; i += 1024) { const float x = base[i]; if (x > mx || (x == mx && i < mi)) { mx = x; mi = i; } }
+    block_argmax1024(mx, mi, rv, ri, tid);
+    float tot = 1.0f;
+    if (p.do_sample) {
+      float part = 0.f;
+      for (int i = tid; i < N; i += 1024) part += expf(base[i] - mx);
+      tot = block_sum1024(part, rv, tid);
+    }
+    for (int c = 0; c < n_keep; ++c) {
+      float best = -INFINITY; int bi = 0x7fffffff;
+      for (int i = tid; i < N; i += 1024) {
+        bool taken = false;
+        for (int o = 0; o < c; ++o) taken = taken || cand_i[o] == i;
+        if (taken) continue;
+        const float x = base[i];
+        const float key = p.do_sample ? (expf(x - mx) / tot) / exp1_draw(p.exp_noise, p.seed, nbase + i) : x;
+        if (key > best || (key == best && i < bi)) { best = key; bi = i; }
+      }
+      block_argmax1024(best, bi, rv, ri, tid);
+      if (tid == 0) { cand_i[c] = bi; cand_s[c] = base[bi]; }
+      __syncthreads();
+    }
   }
   if (tid == 0) {
     // candidates by score, descending (transformers_generation_utils.py:3511-3513; stable)

@@ -38,6 +38,7 @@ from __future__ import annotations
 
 import collections
 import concurrent.futures
+import contextlib
 import threading
 import time
 from typing import Optional
@@ -77,7 +78,7 @@ class _Request:
 
 class BatchPipeline:
     def __init__(self, tts, decode_lanes: int = 3, acoustic_workers: int = 1, coalesce: int = 1, lane_priority: str = "high",
-                 acoustic_coalesce: int = 1):
+                 acoustic_coalesce: int = 1, exclusive: bool = False):
         if decode_lanes < 1 or acoustic_workers < 1 or coalesce < 1 or acoustic_coalesce < 1:
             raise ValueError("decode_lanes, acoustic_workers, coalesce and acoustic_coalesce must be >= 1")
         self.tts = tts
@@ -97,6 +98,9 @@ class BatchPipeline:
         self._streams = []                     # every worker thread's stream (handed back to the library in close())
         self._running = 0                      # requests taken by a lane and not yet retired
         self._groups_taken = 0                 # decode groups formed since the pipeline was last idle
+        # exclusive: a decode job and an acoustic job never share the chip (each takes this lock for the whole of its GPU work) -- the
+        # pipeline then only re-orders and merges the work; measured against the overlapped schedule in profiles/README.md "Round 4"
+        self._turn = threading.Lock() if exclusive else contextlib.nullcontext()
         self.trace = None                      # set to a list to record (kind, start, end, rows) host times of every job (time.perf_counter)
         tts.gpt.MAX_WORKSPACES = max(tts.gpt.MAX_WORKSPACES, decode_lanes + 2)
 
@@ -162,7 +166,7 @@ class BatchPipeline:
                 sg.wait_event(r.ready)
             text = group[0].text if len(group) == 1 else torch.cat([torch.as_tensor(r.text).cpu() for r in group])      # equal widths
             subs = []
-            with torch.cuda.stream(sg):
+            with self._turn, torch.cuda.stream(sg):
                 st = self.tts.gpt_stage(text, group[0].cond, max_mel_tokens=group[0].max_mel_tokens,
                                         repetition_penalty=group[0].repetition_penalty, sampling=group[0].sampling)
                 # every request's rows as its own state, cut on the LANE's stream: the slicing copies below are launches like any
@@ -176,10 +180,10 @@ class BatchPipeline:
                                  "code_lens_t": st["code_lens_t"][a:b].clone(), "latent": st["latent"][a:b, :n].contiguous(),
                                  "times": dict(st["times"])})
                     a = b
-            # The lane waits for its own stream on the host (the decode has synchronised already, what is left is the latent
-            # pass and the slices): a device-side event wait from the acoustic stream is not an option -- HIP refuses to wait on an
-            # event whose stream is capturing, and this lane may be capturing the next batch's decode step by then.
-            sg.synchronize()
+                # The lane waits for its own stream on the host (the decode has synchronised already, what is left is the latent
+                # pass and the slices): a device-side event wait from the acoustic stream is not an option -- HIP refuses to wait on an
+                # event whose stream is capturing, and this lane may be capturing the next batch's decode step by then.
+                sg.synchronize()
             if self.trace is not None:
                 self.trace.append(("decode", t0, time.perf_counter(), int(text.shape[0])))
             for r, sub in zip(group, subs):      # every request's rows go to its own acoustic job
@@ -229,7 +233,7 @@ class BatchPipeline:
             torch.cuda.set_device(self.device)
             t0 = time.perf_counter()
             sa = self._stream("acoustic")
-            with torch.cuda.stream(sa):
+            with self._turn, torch.cuda.stream(sa):
                 if len(group) == 1:
                     st, noise = group[0][1], group[0][0].noise
                 else:
