@@ -724,7 +724,8 @@ def main() -> int:
         if args.workload == "pipeline" and args.gpt_weights != "f32":
             dtype += f"; GPT linear weights STORED as {args.gpt_weights} (rounded once at load, widened to fp32 in registers)"
         if args.workload in ("pipeline", "longform") and desc.get("gpt_kv_cache") == "bf16":
-            dtype += "; KV cache STORED as bf16 (rounded once when a key / value is produced, widened to fp32 in registers)"
+            dtype += ("; KV cache STORED as bf16 (rounded once when a key / value is produced, widened to fp32 in registers; the prefill that "
+                      "fills it runs on the split-bf16 GEMMs, the one that fills an fp32 cache on the exact fp32 MFMA)")
         audio_total = audio_s_per_step_per_gpu * world * args.steps
         value = audio_total / elapsed
         cfgd = dict(desc)

@@ -291,8 +291,11 @@ size_t GPTModel::workspace_bytes(int B, int S, int max_new) const { return carve
 
 // one transformer layer over M = B*S token rows (prefill / latent pass)
 int GPTModel::layer_full(int li, const Buffers& w, int B, int S, const int* kstart, bool store_kv, hipStream_t st) {
-  // prefill (store_kv) feeds the greedy decode: exact fp32.  Latent pass: mode-dependent (split-bf16 by default).
-  auto mm = [&](const LinearWeights& lw, const GemmArgs& ga) { return store_kv ? gemm_tn_forward(lw, ga, st) : gemm_forward(lw, ga, st); };
+  // The prefill (store_kv) that fills an fp32 KV cache feeds an exact greedy decode: exact fp32 MFMA.  With a bf16 cache its keys and
+  // values are rounded to 8 bits on the way in (relative 2^-9), which buries the split-bf16 GEMM's 2^-16 product error: that prefill
+  // runs like the latent pass, mode-dependent (split-bf16 by default, 3-4 x the exact kernel's rate).
+  const bool exact = store_kv && kv_fmt == 0;
+  auto mm = [&](const LinearWeights& lw, const GemmArgs& ga) { return exact ? gemm_tn_forward(lw, ga, st) : gemm_forward(lw, ga, st); };
   const GPTLayer& L = layers[li];
   const int d = cfg.model_dim, M = B * S;
   RowsNormArgs n1;
@@ -310,7 +313,7 @@ int GPTModel::layer_full(int li, const Buffers& w, int B, int S, const int* ksta
   a.q_bs = a.k_bs = a.v_bs = (long)S * 3 * d; a.o_bs = (long)S * d;
   a.q_ts = a.k_ts = a.v_ts = 3 * d; a.o_ts = d;
   a.B = B; a.H = cfg.heads; a.Sq = S; a.Sk = S; a.causal = 1; a.kstart = kstart; a.scale = 0.125f;
-  a.split_bf16 = !store_kv && get_gemm_mode() == GEMM_BF16X3;      // the cache-building prefill stays exact fp32
+  a.split_bf16 = !exact && get_gemm_mode() == GEMM_BF16X3;      // the prefill of an fp32 cache stays exact fp32
   if (flash_attn_forward(a, st)) return 1;
   GemmArgs p;
   p.x = w.att; p.ldx = d; p.y = w.x; p.ldy = d; p.res = w.x; p.ldr = d; p.M = M;
