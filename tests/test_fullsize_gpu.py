@@ -232,7 +232,11 @@ def test_beam_search_at_full_size_16_utterances_vs_oracle(device, full):
 def test_bf16_weights_and_kv_cache_16_utterances_vs_oracle(device, full):
     """configs[2]'s decode as bench.py runs it: the full-size GPT, 16 utterances (20 heads x 16 = 320 attention workgroups, no key
     split), bf16 weight streams AND the bf16 KV cache -- the first 16 greedy codes of every utterance against the CPU oracle on
-    the read-back rounded model with the same key / value rounding (kv_round), ragged text lengths (left padding)."""
+    the read-back rounded model with the same key / value rounding (kv_round), ragged text lengths (left padding).  The rule of this
+    mode (bench.py LOGIT_NOISE_BOUND): a key / value that two fp32 summation orders -- or the prefill's split-bf16
+    GEMM and the oracle's fp32 one -- leave one ulp apart may round to the other bf16 neighbour, which moves a logit by up to 1.5e-2
+    (measured 6e-3..7e-3); so a row either equals the oracle or leaves it at a step where the ORACLE's own margin between its token
+    and the row's is below that bound, and at most two of the 16 rows do.  (The teacher-forced test below bounds every logit.)"""
     from indextts_amd.gpt import UnifiedVoice
     from oracle import gpt as og
     cfg, wg, ws, wv = full
@@ -248,8 +252,11 @@ def test_bf16_weights_and_kv_cache_16_utterances_vs_oracle(device, full):
     lat, emo = c.spk_cond_latent.expand(B, -1, -1), c.emo_vec.expand(B, -1)
     torch.set_num_threads(16)
     with torch.no_grad():
-        ref = og.generate_greedy(tw, g, og.conds_latent(tw, g, lat, emo), text, NEW, 10.0, kv_round=True)
+        conds = og.conds_latent(tw, g, lat, emo)
+        ref, ref_logits = og.generate_greedy(tw, g, conds, text, NEW, 10.0, return_logits=True, kv_round=True)
+        fake = og.prepare_gpt_inputs(tw, g, conds, text)[0]
     from indextts_amd import _lib
+    from test_gpt_gpu import _assert_equal_or_near_tie
     assert _lib.get_decode_geometry() is False
     try:
         for narrow in (False, True):      # idxtts_set_decode_geometry: the 1024-thread GEMVs and the 512-thread ones a serving loop selects
@@ -257,7 +264,8 @@ def test_bf16_weights_and_kv_cache_16_utterances_vs_oracle(device, full):
             assert _lib.get_decode_geometry() is narrow
             codes, _ = uv.inference_speech(lat, text, emo_vec=emo, max_generate_length=NEW, do_sample=False, num_beams=1, repetition_penalty=10.0)
             got = codes.cpu().numpy()
-            assert got.shape == tuple(ref.shape) and np.array_equal(got, ref.numpy()), narrow
+            assert got.shape == tuple(ref.shape), narrow
+            assert _assert_equal_or_near_tie(got, ref.numpy(), ref_logits, fake, 1.5e-2) <= 2, narrow
     finally:
         _lib.set_decode_geometry(False)
 
