@@ -11,6 +11,7 @@
 // A tap is a shifted ROW, so every dilation / tap offset is a plain ds_read_b128 (16-byte slot swizzled by row bit 3:
 // conflict-free).  Weights are permuted once at load from the fp32 pack into per-sub-tile [hl][g2][i32][8] bf16 images
 // (same 2 KiB per sub-tile and tap).
+#include <cstdlib>
 #include <cstring>
 
 #include "conv1d.h"
@@ -70,6 +71,8 @@ struct ConvKP16 {
   int ups_log2;
   int xt;                 // x tile rows (BN + (K-1)*dil)
   int ntiles_row, ntiles, nt8;
+  int mblocks, walk;      // walk 0: row blocks slowest (an XCD sweeps the time tiles of ONE row block: its weight slice stays in L2, x is re-read per row block)
+                          //      1: row blocks fastest (the row blocks of one time tile run side by side on an XCD: x is read from HBM once, weights stream through L2)
   float scale;
   int accum;
   const int* lens; int len_mul_out;
@@ -106,8 +109,8 @@ __device__ __forceinline__ void conv1d_bf16x3_body(const ConvKP16& p) {
   char* Xs = smem16 + NRING * WSLOT;           // [2][hl][XT_MAX][16 ci] bf16
 
   const int L = blockIdx.x, xcd = L & 7, q = L >> 3;
-  const int m_blk = q / p.nt8;
-  const int n_idx = (q - m_blk * p.nt8) * 8 + xcd;
+  const int m_blk = p.walk ? q % p.mblocks : q / p.nt8;
+  const int n_idx = (p.walk ? q / p.mblocks : q - m_blk * p.nt8) * 8 + xcd;
   if (n_idx >= p.ntiles) return;
   const int b = n_idx / p.ntiles_row;
   const int t0 = (n_idx - b * p.ntiles_row) * BN;
@@ -302,6 +305,10 @@ static int launch_conv16(const ConvWeights& w, const ConvArgs& a, hipStream_t st
   p.nt8 = cdiv(p.ntiles, 8);
   p.scale = a.scale; p.accum = a.accum; p.lens = a.lens; p.len_mul_out = a.len_mul_out;
   const int mblocks = cdiv(w.M, BM);
+  // row blocks fastest by default (x leaves HBM once per launch instead of once per row block; measured in profiles/README.md "Round 4");
+  // IDXTTS_CONV_WALK=0 restores the row-blocks-slowest walk for that comparison
+  static const int walk_env = [] { const char* e = getenv("IDXTTS_CONV_WALK"); return e ? atoi(e) : 1; }();
+  p.mblocks = mblocks; p.walk = (walk_env == 1 && mblocks > 1) ? 1 : 0;
   constexpr int NWL = (NSUB * 128 + 255) / 256;
   const size_t lds = (size_t)3 * (NSUB == 1 ? 2048 : NWL * 4096) + (size_t)2 * 2 * XT_MAX * XROW_B;
   const size_t w_bytes = (size_t)cdiv(w.M, CONV_MT) * w.nchunk * w.K * 2048;
