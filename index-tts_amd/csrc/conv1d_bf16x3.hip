@@ -305,10 +305,14 @@ static int launch_conv16(const ConvWeights& w, const ConvArgs& a, hipStream_t st
   p.nt8 = cdiv(p.ntiles, 8);
   p.scale = a.scale; p.accum = a.accum; p.lens = a.lens; p.len_mul_out = a.len_mul_out;
   const int mblocks = cdiv(w.M, BM);
-  // row blocks fastest by default (x leaves HBM once per launch instead of once per row block; measured in profiles/README.md "Round 4");
-  // IDXTTS_CONV_WALK=0 restores the row-blocks-slowest walk for that comparison
-  static const int walk_env = [] { const char* e = getenv("IDXTTS_CONV_WALK"); return e ? atoi(e) : 1; }();
-  p.mblocks = mblocks; p.walk = (walk_env == 1 && mblocks > 1) ? 1 : 0;
+  // Tile walk, per shape (FETCH_SIZE per launch under both walks: profiles/r04_conv_walk_pmc.txt): row blocks fastest -- x leaves HBM once,
+  // the row blocks' weight slices stream through the XCD's L2 once per round of resident workgroups -- unless the layer's weights are so
+  // large (> 20 MB: the first upsampler, the 768-channel k = 11 convolutions) that this stream outweighs the x re-reads it saves.
+  // IDXTTS_CONV_WALK = 0 / 1 forces one walk for that comparison.
+  static const int walk_env = [] { const char* e = getenv("IDXTTS_CONV_WALK"); return e ? atoi(e) : -1; }();
+  const double weight_bytes = 4.0 * w.M * (double)w.Cin * w.K;
+  p.mblocks = mblocks;
+  p.walk = mblocks > 1 && (walk_env >= 0 ? walk_env == 1 : weight_bytes <= 20e6) ? 1 : 0;
   constexpr int NWL = (NSUB * 128 + 255) / 256;
   const size_t lds = (size_t)3 * (NSUB == 1 ? 2048 : NWL * 4096) + (size_t)2 * 2 * XT_MAX * XROW_B;
   const size_t w_bytes = (size_t)cdiv(w.M, CONV_MT) * w.nchunk * w.K * 2048;

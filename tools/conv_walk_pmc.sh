@@ -17,6 +17,7 @@ import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["Counter_Name"] == sys.argv[3]]
 v = [float(r["Counter_Value"]) for r in rows]
 print(f"walk {sys.argv[2]} {sys.argv[3]}: launches {len(v)}, mean per launch {sum(v)/len(v):.1f} KiB (raw), total {sum(v)/1048576:.2f} GiB (raw)")
+print("   per launch, MiB (raw), in launch order: " + " ".join(f"{x/1024:.0f}" for x in v))
 PY
   done
 done
