@@ -272,7 +272,7 @@ def build_pipeline(args, world, rank, dev):
                                                       coalesce=max(1, args.coalesce), lane_priority=args.lane_priority,
                                                       acoustic_coalesce=max(1, args.acoustic_coalesce), exclusive=args.exclusive)
     # batches submitted and not yet retired: every lane full plus what one acoustic batch takes
-    in_flight = lanes * max(1, args.coalesce) + max(1, args.acoustic_coalesce)
+    in_flight = args.in_flight if args.in_flight > 0 else lanes * max(1, args.coalesce) + max(1, args.acoustic_coalesce)
     if pipe is not None and args.trace_jobs:
         pipe.trace = []
     pending = []
@@ -532,6 +532,7 @@ def main() -> int:
     ap.add_argument("--acoustic-coalesce", type=int, default=1, help="pipeline workload: a free acoustic worker takes up to this many decoded requests as one s2mel + vocoder batch")
     ap.add_argument("--coalesce", type=int, default=1,
                     help="pipeline workload: a free decode lane takes up to this many waiting 16-utterance requests and decodes them as one batch")
+    ap.add_argument("--in-flight", type=int, default=0, help="pipeline workload: batches submitted and not yet retired (0 = decode lanes x merged requests + one acoustic batch)")
     ap.add_argument("--exclusive", action="store_true",
                     help="pipeline workload: a decode job and an acoustic job never share the chip (BatchPipeline(exclusive=True)): the "
                          "pipeline only merges and re-orders")

@@ -662,7 +662,7 @@ int idxtts_get_decode_geometry(void) { return get_decode_geometry(); }
 int idxtts_release_stream(void* stream) {
   API_BEGIN
   hipStream_t st = static_cast<hipStream_t>(stream);
-  return gemm_release_stream_scratch(st) || s2mel_release_stream(st);
+  return gemm_release_stream_scratch(st) || gemm_tn_release_stream_scratch(st) || s2mel_release_stream(st);
   API_END
 }
 

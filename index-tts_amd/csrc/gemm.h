@@ -65,5 +65,6 @@ int gemm_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t stream);
 bool gemm_uses_planes(const LinearWeights& w, const GemmArgs& a);
 
 int gemm_release_stream_scratch(hipStream_t stream);      // idxtts_release_stream: the split-plane scratch kept per stream
+int gemm_tn_release_stream_scratch(hipStream_t stream);   // ... and the exact kernel's K-group combine scratch
 
 }  // namespace idxtts

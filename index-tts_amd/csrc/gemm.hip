@@ -18,6 +18,8 @@
 // an XCD share one weight slice in their L2 while streaming different activation rows.
 #include <algorithm>
 #include <cmath>
+#include <map>
+#include <mutex>
 
 #include "gemm_common.h"
 #include "prof.h"
@@ -56,6 +58,25 @@ void pack_linear_kn(float* dst, const float* w_kn, int K, int N) {
 
 constexpr int XBLK = 132;   // floats per padded [32 rows][4] sub-block (528 B)
 
+// per-(device, stream) scratch of the few-tile launches' K-group combine: [4 KiB arrival counters][partial tiles]
+struct SplitKScratch { void* ptr = nullptr; size_t bytes = 0; };
+static std::map<std::pair<int, hipStream_t>, SplitKScratch> g_sk;
+static std::mutex g_sk_mu;
+int gemm_tn_release_stream_scratch(hipStream_t stream) {
+  int dev_id = 0;
+  IDX_HIP(hipGetDevice(&dev_id));
+  SplitKScratch sc;
+  {
+    std::lock_guard<std::mutex> lock(g_sk_mu);
+    auto it = g_sk.find(std::make_pair(dev_id, stream));
+    if (it == g_sk.end()) return 0;
+    sc = it->second;
+    g_sk.erase(it);
+  }
+  if (sc.ptr) IDX_HIP(hipFreeAsync(sc.ptr, stream));
+  return 0;
+}
+
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmKP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float (*Xs)[4 * 2 * 4 * XBLK] = reinterpret_cast<float (*)[4 * 2 * 4 * XBLK]>(smem);
@@ -67,7 +88,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmKP p) {
   //   n_fast = 0 (big W, few rows: GPT prefill): all m-tiles of one n-block back to back -> W streams once per XCD
   const int L = blockIdx.x, xcd = L & 7, q = L >> 3;
   int bn, bm;
-  if (p.n_fast) { const int bml = q / p.nblocks; bn = q - bml * p.nblocks; bm = bml * 8 + xcd; }
+  if (p.direct_map) { bn = L / p.mtiles; bm = L - bn * p.mtiles; }      // few tiles: one per workgroup id, spread over all XCDs
+  else if (p.n_fast) { const int bml = q / p.nblocks; bn = q - bml * p.nblocks; bm = bml * 8 + xcd; }
   else { bn = q / p.mt8; bm = (q - bn * p.mt8) * 8 + xcd; }
   if (bm >= p.mtiles) return;
 
@@ -128,16 +150,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmKP p) {
     }
   };
 
-  f32x16 acc[2][2];
+  // acc: the K group in progress; tot: the finished groups, added in group order (see GemmKP::kg)
+  f32x16 acc[2][2], tot[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) { acc[a][b][r] = 0.0f; tot[a][b][r] = 0.0f; }
 
   int ksteps = (p.kc16 + 1) >> 1, ks0 = 0;
   if (p.ksplit > 1) { ks0 = blockIdx.y * p.ksteps_per_split; ksteps = min(ksteps, ks0 + p.ksteps_per_split); }
+  int in_group = ks0 % p.kg;
   load_tiles(ks0);
   store_tiles(ks0 & 1);
   __syncthreads();
@@ -164,18 +188,74 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmKP p) {
             for (int nt = 0; nt < 2; ++nt)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
       }
+    if (++in_group == p.kg || !has_next) {      // a K group is complete (or the range ends)
+      in_group = 0;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { tot[mt][nt][r] += acc[mt][nt][r]; acc[mt][nt][r] = 0.0f; }
+    }
     if (has_next) store_tiles((ks + 1) & 1);
     __syncthreads();
   }
 
+  if (p.sk_cnt) {
+    // one K group per workgroup: the partial tile goes to the slab in register order (write-through 16-byte stores: [group][tile][16][256
+    // threads]), the last workgroup of the tile to arrive adds the groups in order
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ int s_last;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.sk_slab, 0, p.sk_slab_bytes, 0x00020000);
+    const int tile = bm * p.nblocks + bn, ntiles = p.mtiles * p.nblocks;
+    const int part_stride = ntiles * 16 * 256 * 16;      // bytes between two groups
+    const int mine = (tile * 16 * 256 + tid) * 16;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const f32x4 v = {tot[mt][nt][4 * r4], tot[mt][nt][4 * r4 + 1], tot[mt][nt][4 * r4 + 2], tot[mt][nt][4 * r4 + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, mine + ((mt * 2 + nt) * 4 + r4) * 4096, (int)blockIdx.y * part_stride, 17);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // acknowledged at the device coherence point before the arrival
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(&p.sk_cnt[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = old == (unsigned)p.ksplit - 1u;
+      if (s_last) __hip_atomic_store(&p.sk_cnt[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[mt][nt][r] = 0.0f;
+    for (int g = 0; g < p.ksplit; ++g) {
+      u32x4 t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, mine + u * 4096, g * part_stride, 16);      // sc1: past the L1
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const f32x4 v = __builtin_bit_cast(f32x4, t[u]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tot[u >> 3][(u >> 2) & 1][4 * (u & 3) + e] += v[e];
+      }
+    }
+    gemm_epilogue(p, tot, bm, bn, wm, wn, h, j);
+    return;
+  }
   if (p.ksplit > 1) {      // raw partial slab of this K range
     GemmKP q = p;
     q.y = p.y + (size_t)blockIdx.y * p.M * p.ldy;
     q.bias = nullptr; q.res = nullptr; q.row_len = nullptr; q.act = ACT_NONE; q.out_scale = 1.0f;
-    gemm_epilogue(q, acc, bm, bn, wm, wn, h, j);
+    gemm_epilogue(q, tot, bm, bn, wm, wn, h, j);
     return;
   }
-  gemm_epilogue(p, acc, bm, bn, wm, wn, h, j);
+  gemm_epilogue(p, tot, bm, bn, wm, wn, h, j);
 }
 
 int gemm_tn_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t stream) {
@@ -209,7 +289,39 @@ int gemm_tn_forward(const LinearWeights& w, const GemmArgs& a, hipStream_t strea
   const int nblocks = cdiv(w.N, 128);
   p.nblocks = nblocks;
   p.n_fast = ((double)w.N * w.K * 4.0 <= 8.0 * 1024 * 1024) && ((double)a.M * w.K > (double)w.N * w.K) ? 1 : 0;
-  const int64_t grid = (int64_t)8 * nblocks * p.mt8;
+  // K groups (GemmKP::kg): a function of K alone, so a row's result never depends on how many rows are computed beside it
+  const int ksteps_all = cdiv(p.kc16, 2);
+  p.kg = std::max(5, cdiv(ksteps_all, 8));
+  const int ngroups = cdiv(ksteps_all, p.kg);
+  p.direct_map = 0; p.sk_slab = nullptr; p.sk_cnt = nullptr; p.sk_slab_bytes = 0;
+  const int tiles = nblocks * p.mtiles;
+  // Few output tiles (a B = 1 prefill, the prompt encoders' projections): one workgroup per tile would leave most CUs idle behind
+  // a K loop of dependent global-load -> LDS -> MFMA steps.  One K group per workgroup instead (up to 8 x the workgroups), combined in
+  // the kernel by the last arriver.
+  if (p.ksplit == 1 && tiles <= 96 && ngroups >= 2) {
+    const size_t slab_bytes = (size_t)ngroups * tiles * 65536, cnt_bytes = 4096;
+    static_assert(96 * 4 <= 4096, "arrival counters");
+    int dev_id = 0;
+    IDX_HIP(hipGetDevice(&dev_id));
+    SplitKScratch* scp = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(g_sk_mu);
+      scp = &g_sk[std::make_pair(dev_id, stream)];
+    }
+    if (scp->bytes < cnt_bytes + slab_bytes) {      // stream-ordered (no device-wide synchronisation), grow-only
+      if (scp->ptr) IDX_HIP(hipFreeAsync(scp->ptr, stream));
+      scp->ptr = nullptr; scp->bytes = 0;
+      IDX_HIP(hipMallocAsync(&scp->ptr, cnt_bytes + slab_bytes, stream));
+      IDX_HIP(hipMemsetAsync(scp->ptr, 0, cnt_bytes, stream));      // counters start at 0 and every launch leaves them at 0
+      scp->bytes = cnt_bytes + slab_bytes;
+    }
+    p.sk_cnt = static_cast<unsigned*>(scp->ptr);
+    p.sk_slab = reinterpret_cast<float*>(static_cast<char*>(scp->ptr) + cnt_bytes);
+    p.sk_slab_bytes = (int)slab_bytes;
+    p.ksplit = ngroups; p.ksteps_per_split = p.kg;
+  }
+  if (tiles <= 96) p.direct_map = 1;
+  const int64_t grid = p.direct_map ? (int64_t)tiles : (int64_t)8 * nblocks * p.mt8;
   IDX_CHECK(grid < (1ll << 31), "grid size");
   const double flops = 2.0 * a.M * (double)w.N * w.K;
   const double bytes = 4.0 * ((double)a.M * w.K + (double)w.N * w.K + (double)a.M * w.N * (a.res ? 2.0 : 1.0));

@@ -21,6 +21,12 @@ struct GemmKP {
   // rope[(m % rope_T)][(col / 2) % 32] = (cos, sin)   (gpt_fast/model.py apply_rotary_emb on q and k of a fused qkv)
   const float* rope; int rope_T; int rope_cols;
   int ksplit, ksteps_per_split;    // exact-fp32 kernel: K loop split over blockIdx.y (raw partial slabs)
+  // exact-fp32 kernel: K is summed in groups of `kg` 32-k steps (a group accumulates from zero, the groups are added in order), whatever
+  // the launch geometry.  Few-tile launches put one group per workgroup (blockIdx.y); the LAST workgroup of an output tile to arrive at
+  // sk_cnt[tile] adds the groups' partial tiles from sk_slab in group order and runs the epilogue -- the same sum, bit for bit, as the
+  // one-workgroup form.  direct_map: tiles dealt to consecutive workgroup ids (= round-robin over the XCDs) instead of the XCD-aware walk.
+  int kg, direct_map;
+  float* sk_slab; unsigned* sk_cnt; int sk_slab_bytes;
 };
 
 

@@ -51,6 +51,25 @@ def test_gemm_tn_vs_torch(device, shape):
     assert (y2 - (gelu + r.double()).float()).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("N,K", [(1280, 1280), (3840, 1280), (1280, 5120), (512, 864), (256, 96)])
+def test_gemm_tn_rows_do_not_depend_on_the_row_count(device, N, K):
+    """A launch with few output tiles puts one K group per workgroup and combines them in the kernel (last arriver); a launch with many tiles
+    runs the whole K loop in one workgroup.  Both add the same K groups in the same order: rows computed alone (split) equal, bit for bit,
+    the same rows inside a 2000-row call (unsplit) -- what keeps a B = 1 prefill identical to its rows in a batched one."""
+    M = 2000
+    x = torch.from_numpy(synth.uniform(f"t/gemm/inv/x/{N}/{K}", (M, K), 1.0))
+    w = torch.from_numpy(synth.fan_in_uniform(f"t/gemm/inv/w/{N}/{K}", (N, K), K))
+    b = torch.from_numpy(synth.uniform(f"t/gemm/inv/b/{N}/{K}", (N,), 0.2))
+    r = torch.from_numpy(synth.uniform(f"t/gemm/inv/r/{N}/{K}", (M, N), 1.0))
+    big = _linear(device, w, b, x, act=1, res=r)
+    for lo, hi in ((0, 77), (130, 258), (1990, 2000)):
+        small = _linear(device, w, b, x[lo:hi].contiguous(), act=1, res=r[lo:hi].contiguous())
+        assert torch.equal(small, big[lo:hi]), (lo, hi)
+    ref = x.double() @ w.double().t() + b.double()
+    gelu = 0.5 * ref * (1 + torch.tanh(math.sqrt(2 / math.pi) * (ref + 0.044715 * ref ** 3)))
+    assert (big - (gelu + r.double()).float()).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("shape", [(256, 128, 32), (300, 1536, 512), (1000, 512, 864), (129, 80, 512), (640, 512, 1536), (513, 8194, 128),
                                    (4100, 1536, 512), (5003, 80, 512), (4096, 320, 96),     # >= 4096 rows: the 256-row tile kernel
                                    (16640, 1024, 512), (16500, 1280, 256)])                # 260 / 325 tiles: K-split tail tiles
