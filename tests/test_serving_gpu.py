@@ -9,11 +9,13 @@ from indextts_amd.config import PipelineConfig
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("lanes,coalesce,workers,acoal", [(1, 1, 1, 1), (3, 1, 1, 1), (2, 3, 2, 1), (1, 4, 1, 1), (3, 1, 1, 2), (2, 2, 1, 3)])
-def test_batch_pipeline_equals_sequential(device, lanes, coalesce, workers, acoal):
+@pytest.mark.parametrize("lanes,coalesce,workers,acoal,exclusive", [(1, 1, 1, 1, False), (3, 1, 1, 1, False), (2, 3, 2, 1, False), (1, 4, 1, 1, False),
+                                                                     (3, 1, 1, 2, False), (2, 2, 1, 3, False), (2, 2, 1, 1, True)])
+def test_batch_pipeline_equals_sequential(device, lanes, coalesce, workers, acoal, exclusive):
     """coalesce > 1: a free lane decodes several waiting requests (different widths and row counts here) as ONE batch and hands each
     request's rows on; acoustic_coalesce > 1: a free acoustic worker takes several decoded requests as ONE s2mel + vocoder batch --
-    the kernels treat rows independently, so every request still equals its own sequential call bit for bit."""
+    the kernels treat rows independently, so every request still equals its own sequential call bit for bit.  exclusive: decode jobs and
+    acoustic jobs take turns on the chip."""
     from indextts_amd.infer_v2 import IndexTTS2, PromptConditioning
     from indextts_amd.serving import BatchPipeline
     cfg = PipelineConfig.tiny()
@@ -43,7 +45,7 @@ def test_batch_pipeline_equals_sequential(device, lanes, coalesce, workers, acoa
             warnings.simplefilter("ignore")
             want = [tts.synthesize_batch(t, cond, max_mel_tokens=M, noise=n) for t, n in zip(texts, noises)]
             torch.cuda.synchronize()
-            with BatchPipeline(tts, decode_lanes=lanes, coalesce=coalesce, acoustic_workers=workers, acoustic_coalesce=acoal) as pipe:
+            with BatchPipeline(tts, decode_lanes=lanes, coalesce=coalesce, acoustic_workers=workers, acoustic_coalesce=acoal, exclusive=exclusive) as pipe:
                 futs = [pipe.submit(t, cond, max_mel_tokens=M, noise=n) for t, n in zip(texts, noises)]
                 got = [f.result() for f in futs]
     finally:
