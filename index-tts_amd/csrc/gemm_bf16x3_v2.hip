@@ -436,11 +436,16 @@ int gemm_bf16x3_v2_forward(GemmKP p, const void* wplanes, const LinearWeights& w
   IDX_CHECK(2 * plane < (1ull << 31) && 2 * b_plane < (1ull << 31), "operand planes beyond the 2 GiB a buffer offset addresses");
   q.a_plane = (int)plane; q.a_bytes = (int)(2 * plane);
   q.b_plane = (int)b_plane; q.b_bytes = (int)(2 * b_plane);
-  // column groups: the smallest power of two that brings an XCD's B slice (hi + lo planes) under ~1.5 MB (in-process A/B,
-  // M = 50 208, K = 512: N = 1536 253 -> 235 us, N = 3072 449 -> 417 us; shapes with one group unchanged)
+  // Column groups: the smallest power of two that brings an XCD's B slice (hi + lo planes) under ~3.2 MB, i.e. next to the streaming A
+  // in its 4 MiB L2.  Time does not depend on the threshold between 1.5 and 7 MB (s2mel 0.497-0.503 s sequential, 183-185 audio-s/s
+  // pipelined); the bytes past the L2 do (profiles/r04_gemm_cs_pmc.txt: mean FETCH_SIZE per launch 289 MiB at 1.5 MB -- A re-read once per
+  // group --, 234 at 3.2, 309 at 7 -- the SwiGLU B no longer fits): 3.2 MB.  A B of up to 8 slices walks the same way (its column groups
+  // keep their slices resident; walking column blocks slowest re-read A once per 128 columns).
   q.cs = 1;
+  static const double cs_bytes = [] { const char* e = getenv("IDXTTS_GEMM_CS_BYTES"); return e ? atof(e) : 3.2e6; }();      // (measurement hook)
+  if (!q.g.n_fast && (double)w.N * w.K * 4.0 <= 8.0 * cs_bytes && a.M > w.N) q.g.n_fast = 1;
   if (q.g.n_fast) {
-    while (q.cs < 8 && (double)w.N * w.K * 4.0 / q.cs > 1.5e6 && q.g.nblocks >= 2 * q.cs) q.cs *= 2;
+    while (q.cs < 8 && (double)w.N * w.K * 4.0 / q.cs > cs_bytes && q.g.nblocks >= 2 * q.cs) q.cs *= 2;
   }
   q.nbg = cdiv(q.g.nblocks, q.cs);
   const int64_t grid = q.g.n_fast ? (int64_t)8 * q.nbg * cdiv(q.g.mtiles, 8 / q.cs) : (int64_t)8 * q.g.nblocks * q.g.mt8;
