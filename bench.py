@@ -329,7 +329,8 @@ def build_pipeline(args, world, rank, dev):
             f"{cfg.diffusion_steps} CFM steps, {cores} threads ...")
         with torch.no_grad():
             c0 = time.perf_counter()
-            r = op.synthesize_one(twg, tws, wv, cfg, ctext, cond0, cnoise, Mc, kv_round=kv16)
+            ctimers = {}
+            r = op.synthesize_one(twg, tws, wv, cfg, ctext, cond0, cnoise, Mc, kv_round=kv16, timers=ctimers)
             cdt = time.perf_counter() - c0
         caudio = r["wav"].shape[-1] / cfg.bigvgan.sampling_rate
         wavs, mid = tts.synthesize_batch(ctext, cond_dev, max_mel_tokens=Mc, noise=cnoise.to(dev), return_intermediates=True)
@@ -387,10 +388,19 @@ def build_pipeline(args, world, rank, dev):
         extra["codes_match_rate"] = par[own]["codes_match_rate_teacher_forced"]
         extra["codes_match_rate_note"] = (f"{PB} utterances x {par[own]['steps']} steps, HIP decode teacher-forced on the oracle's codes (KV {own}); "
                                           "free-running prefix match rate and the exact mode under decode_parity")
+        # BASELINE.md 3's B = 16 leg, from the measured B = 1 stage times: the oracle's greedy decode streams the 1.9 GB of GPT weights once per
+        # step whatever the number of rows (its step time at 16 rows is taken as the 1-row time: a LOWER bound on the time, an upper bound on the
+        # rate), s2mel and BigVGAN work is per utterance (x 16)
+        b16_s = ctimers.get("gpt", 0.0) + 16.0 * (ctimers.get("s2mel", 0.0) + ctimers.get("bigvgan", 0.0))
+        extra["stage_seconds"] = {k: round(v, 2) for k, v in ctimers.items()}
+        extra["batch16_estimate"] = {"value": round(16.0 * caudio / b16_s, 4) if b16_s > 0 else None, "unit": "audio_s/s",
+                                     "how": "16 x this utterance: decode time of ONE row (weight-stream-bound on the CPU: an upper bound on the rate) "
+                                            "+ 16 x (s2mel + BigVGAN) of the measured stage times; the full 16 x 512-code batch would take ~20 minutes"}
         return {"value": round(caudio / cdt, 4), "unit": "audio_s/s", "cores": cores, "kind": "port",
                 "sample": f"oracle/pipeline.py (fp32 torch CPU): 1 utterance, {Lc} text tokens, {Mc} codes ({caudio:.2f} s audio), "
                           f"Tp={Tp}, {cfg.diffusion_steps} CFM steps, full-size weights (the B = 16 x 512-code batch of the GPU run would "
-                          f"take the oracle ~20 minutes: BASELINE.md 3's B = 16 leg does not fit the bounded sample)",
+                          f"take the oracle ~20 minutes: BASELINE.md 3's B = 16 leg does not fit the bounded sample; batch16_estimate derives it "
+                          f"from this sample's stage times)",
                 **extra,
                 "greedy_codes_equal_vs_gpu": codes_equal, "mel_l1_vs_gpu": mel_l1, "wav_max_abs_diff_vs_gpu_fullscale": wav_err}
 

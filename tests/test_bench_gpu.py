@@ -34,6 +34,8 @@ def test_bench_json_contract():
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1
     assert cb["mel_l1_vs_gpu"] <= 1e-3
+    # the B = 16 leg of the CPU baseline is derived from the measured stage times of the one-utterance sample (and says so)
+    assert set(cb["stage_seconds"]) == {"gpt", "s2mel", "bigvgan"} and cb["batch16_estimate"]["value"] >= cb["value"]
     # The parity rule of the headline mode (bf16 KV cache) and of the exact mode (fp32 cache), 4 utterances x 64 teacher-forced steps on
     # the full-size model: logit noise within the stated bound, every differing argmax a near-tie of the oracle, the free-running decode
     # leaving the oracle's sequence only there.  Codes may differ in the bf16 mode -- then only at such a step.
