@@ -161,6 +161,14 @@ int idxtts_attention_fwd(const float* q, const float* k, const float* v, float* 
 int idxtts_attention_bf16x3_fwd(const float* q, const float* k, const float* v, float* o, long q_batch_stride, int q_token_stride,
                          long kv_batch_stride, int kv_token_stride, long o_batch_stride, int o_token_stride, int B, int H,
                          int Sq, int Sk, int causal, const int* kstart, const int* kend, float scale, void* stream);
+/* Non-causal self-attention (head_dim 64) with the "relative_key" distance embedding of the w2v-bert-2.0 encoder the reference's prompt block
+ * runs (indextts/infer_v2.py:633-638 get_emb -> transformers Wav2Vec2BertSelfAttention, position_embeddings_type="relative_key"):
+ *   scores[i][j] = scale * (q_i . k_j + q_i . rel_key[clamp(j - i, -rel_left, rel_right) + rel_left]),   rel_key [rel_left + rel_right + 1][64]
+ * (one table for every head, at most 96 rows), keys >= kend[b] masked.  q / k / v share one batch / token stride (a fused qkv buffer);
+ * split_bf16 = 0: exact-fp32 MFMAs, 1: split-bf16 products. */
+int idxtts_attention_relkey_fwd(const float* q, const float* k, const float* v, float* o, long batch_stride, int token_stride,
+                                long o_batch_stride, int o_token_stride, int B, int H, int S, const int* kend, float scale,
+                                const float* rel_key, int rel_left, int rel_right, int split_bf16, void* stream);
 /* y = LayerNorm(x) * gamma + beta over the last dim (eps), rows of length d. */
 int idxtts_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, int M, int d, float eps, void* stream);
 

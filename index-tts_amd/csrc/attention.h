@@ -15,6 +15,11 @@ struct AttnArgs {
   float scale = 0.125f;
   void* o_planes = nullptr;       // split_bf16 only: write the output as split-bf16 planes over rows b*Sq + q, columns head*64 + d (o may be null)
   int split_bf16 = 0;             // 1: split-bf16 products (3 bf16 MFMAs each, ~2^-16 relative) instead of exact-fp32 MFMAs
+  // "relative_key" distance embedding (HF Wav2Vec2BertSelfAttention): scores[i][j] += scale * q_i . rel_key[clamp(j - i, -rel_left,
+  // rel_right) + rel_left]; rel_key [rel_left + rel_right + 1][64] fp32, one table for every head (<= 96 rows); non-causal self-attention
+  // only.  The kernel multiplies the table by its queries once per workgroup (three more 32-row "key" tiles through the same MFMAs) and
+  // keeps the products in LDS: a tile of keys outside a wave's band adds one per-query constant, a tile inside it a per-element lookup.
+  const float* rel_key = nullptr; int rel_left = 0, rel_right = 0;
 };
 
 int flash_attn_forward(const AttnArgs& a, hipStream_t stream);

@@ -36,6 +36,26 @@ __device__ __forceinline__ float xor32_sum(float v) {
 
 constexpr int KROW = 68;     // K tile row stride (floats): 64 + 4 pad -> conflict-free ds_read_b128 fragments
 constexpr float NEG_BIG = -1e30f;
+constexpr int REL_MAX = 96;  // rows of a relative_key table (three 32-row tiles)
+constexpr int REL_ROW = 97;  // floats per query in the LDS table of q . rel_key products (odd: lanes = queries hit distinct banks)
+constexpr int REL_LDS = 4 * 32 * REL_ROW * (int)sizeof(float);      // dynamic LDS of a relative_key launch: one table per wave
+
+// scores of one 32 x 32 tile (register r of lane half h = key key0 + (r & 3) + 8 (r >> 2) + 4 h, lane j = query qi) += the relative_key
+// term from the wave's table
+__device__ __forceinline__ void add_rel_term(f32x16& s, const float* tbl_row, int key0, int q0, int qi, int h, int L, int R) {
+  const int dmin = key0 - (q0 + 31), dmax = key0 + 31 - q0;      // range of key - query over the tile (wave-uniform)
+  if (dmax <= -L || dmin >= R) {
+    const float c = tbl_row[dmax <= -L ? 0 : L + R];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] += c;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      s[r] += tbl_row[min(max(key - qi, -L), R) + L];
+    }
+  }
+}
 
 __global__ __launch_bounds__(256) void flash_attn_f32_kernel(const AttnArgs p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 32 * KROW + 2 * 32 * 64];
@@ -105,6 +125,34 @@ __global__ __launch_bounds__(256) void flash_attn_f32_kernel(const AttnArgs p) {
     for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
   float m_run = NEG_BIG, l_run = 0.0f;
 
+  extern __shared__ float rel_dyn[];
+  float* const tbl_row = rel_dyn + (wave * 32 + j) * REL_ROW;      // this lane's query
+  if (p.rel_key) {      // q . rel_key[r] for this workgroup's queries: the table's rows go through the K tile and the QK MFMAs
+    const int nrel = p.rel_left + p.rel_right + 1;
+    for (int rt = 0; rt * 32 < nrel; ++rt) {
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        const int idx = tid + 256 * l, row = idx >> 4, c4 = idx & 15, rr = rt * 32 + row;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (rr < nrel) a = *reinterpret_cast<const f32x4*>(p.rel_key + (size_t)rr * 64 + c4 * 4);
+        *reinterpret_cast<f32x4*>(&Ks[0][row * KROW + c4 * 4]) = a;
+      }
+      __syncthreads();
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks[0] + j * KROW + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[g][e], s, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tbl_row[rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = s[r];
+      __syncthreads();
+    }
+  }
+
   if (ntiles > 0) {
     load_kv(0);
     store_kv(0);
@@ -129,6 +177,7 @@ __global__ __launch_bounds__(256) void flash_attn_f32_kernel(const AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[g][e], s, 0, 0, 0);
       }
+      if (p.rel_key) add_rel_term(s, tbl_row, key0, q0, qi, h, p.rel_left, p.rel_right);
       // ---- mask + online softmax (query = lane, keys = registers of both lane halves) ----
       float mx = NEG_BIG;
 #pragma unroll
@@ -292,6 +341,39 @@ __global__ __launch_bounds__(256) void flash_attn_bf16x3_kernel(const AttnArgs p
   // transposing V read: lane 4q+p of a 16-lane group addresses row (key) q, columns 4p..4p+3 of the group's 16 columns
   const int v_off = 64 * KB16 + (4 * h + ((lane & 15) >> 2)) * VB16 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 
+  extern __shared__ float rel_dyn[];
+  float* const tbl_row = rel_dyn + (wave * 32 + j) * REL_ROW;      // this lane's query
+  if (p.rel_key) {      // q . rel_key[r] for this workgroup's queries: the table's rows go through the K planes and the QK MFMAs
+    const int nrel = p.rel_left + p.rel_right + 1;
+    for (int rt = 0; rt * 32 < nrel; ++rt) {
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        const int idx = tid + 256 * l, row = idx >> 4, c4 = idx & 15, rr = rt * 32 + row;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (rr < nrel) a = *reinterpret_cast<const f32x4*>(p.rel_key + (size_t)rr * 64 + c4 * 4);
+        bf16x4 hi, lo;
+        split4(a, hi, lo);
+        *reinterpret_cast<bf16x4*>(smem + row * KB16 + c4 * 8) = hi;
+        *reinterpret_cast<bf16x4*>(smem + 32 * KB16 + row * KB16 + c4 * 8) = lo;
+      }
+      __syncthreads();
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(smem + k_off + 32 * c);
+        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(smem + 32 * KB16 + k_off + 32 * c);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[c], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[c], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[c], s, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tbl_row[rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = s[r];
+      __syncthreads();
+    }
+  }
+
   if (ntiles > 0) {
     load_kv(0);
     store_kv(0);
@@ -316,6 +398,7 @@ __global__ __launch_bounds__(256) void flash_attn_bf16x3_kernel(const AttnArgs p
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[c], s, 0, 0, 0);
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[c], s, 0, 0, 0);
       }
+      if (p.rel_key) add_rel_term(s, tbl_row, key0, q0, qi, h, p.rel_left, p.rel_right);
       // ---- mask (boundary tiles only: wave-uniform test) + online softmax in the log2 domain ----
       const bool need_mask = key0 < kstart || key0 + 32 > kend || (p.causal && key0 + 31 > q0);
       float mx = NEG_BIG;
@@ -722,8 +805,21 @@ int flash_attn_forward(const AttnArgs& a, hipStream_t stream) {
   const double bytes = 4.0 * a.B * a.H * 64.0 * (2.0 * a.Sq + 2.0 * a.Sk);
   static const int cat_x3 = prof_register("flash_attn_bf16x3_kernel"), cat_f32 = prof_register("flash_attn_f32_kernel");
   ProfScope prof(a.split_bf16 ? cat_x3 : cat_f32, stream, flops, bytes);
-  if (a.split_bf16) hipLaunchKernelGGL(flash_attn_bf16x3_kernel, grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(flash_attn_f32_kernel, grid, dim3(256), 0, stream, a);
+  size_t dyn = 0;
+  if (a.rel_key) {
+    IDX_CHECK(a.rel_left >= 0 && a.rel_right >= 0 && a.rel_left + a.rel_right + 1 <= REL_MAX && !a.causal && a.Sq == a.Sk && !a.kstart,
+              "relative_key: non-causal self-attention, at most 96 distances");
+    IDX_CHECK((reinterpret_cast<uintptr_t>(a.rel_key) & 15) == 0, "rel_key must be 16-byte aligned");
+    dyn = REL_LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+      IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, REL_LDS));
+      IDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, REL_LDS));
+      attr_set = true;
+    }
+  }
+  if (a.split_bf16) hipLaunchKernelGGL(flash_attn_bf16x3_kernel, grid, dim3(256), dyn, stream, a);
+  else hipLaunchKernelGGL(flash_attn_f32_kernel, grid, dim3(256), dyn, stream, a);
   IDX_LAUNCH_CHECK();
   return 0;
 }

@@ -287,6 +287,21 @@ int idxtts_attention_fwd(const float* q, const float* k, const float* v, float* 
   API_END
 }
 
+int idxtts_attention_relkey_fwd(const float* q, const float* k, const float* v, float* o, long batch_stride, int token_stride,
+                                long o_batch_stride, int o_token_stride, int B, int H, int S, const int* kend, float scale,
+                                const float* rel_key, int rel_left, int rel_right, int split_bf16, void* stream) {
+  API_BEGIN
+  IDX_CHECK(rel_key, "rel_key is null");
+  AttnArgs a;
+  a.q = q; a.k = k; a.v = v; a.o = o;
+  a.q_bs = a.k_bs = a.v_bs = batch_stride; a.o_bs = o_batch_stride;
+  a.q_ts = a.k_ts = a.v_ts = token_stride; a.o_ts = o_token_stride;
+  a.B = B; a.H = H; a.Sq = S; a.Sk = S; a.causal = 0; a.kend = kend; a.scale = scale;
+  a.rel_key = rel_key; a.rel_left = rel_left; a.rel_right = rel_right; a.split_bf16 = split_bf16 ? 1 : 0;
+  return flash_attn_forward(a, static_cast<hipStream_t>(stream));
+  API_END
+}
+
 int idxtts_attention_bf16x3_fwd(const float* q, const float* k, const float* v, float* o, long q_batch_stride, int q_token_stride,
                          long kv_batch_stride, int kv_token_stride, long o_batch_stride, int o_token_stride, int B, int H,
                          int Sq, int Sk, int causal, const int* kstart, const int* kend, float scale, void* stream) {

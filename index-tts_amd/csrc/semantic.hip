@@ -17,6 +17,7 @@
 
 #include "model_util.h"
 #include "semantic.h"
+#include "attention.h"
 
 namespace idxtts {
 
@@ -157,11 +158,24 @@ int W2VBertModel::forward(const float* feats, const int* lens_host, int B, int T
     // self-attention with the relative_key distance embedding
     if (ln(x, w.h, L.att_g, L.att_b)) return 1;
     if (lin(L.qkv, w.h, D, w.qkv, 3 * D, M, st)) return 1;
-    SeqAttnArgs a;
-    a.q = w.qkv; a.k = w.qkv + D; a.v = w.qkv + 2 * D; a.ldq = a.ldk = a.ldv = 3 * D; a.q_bs = a.k_bs = a.v_bs = (long)T * 3 * D;
-    a.o = w.att; a.ldo = D; a.o_bs = (long)T * D; a.kend = w.len; a.B = B; a.H = H; a.Sq = T; a.Sk = T; a.dk = dk; a.scale = att_scale;
-    a.rel_key = L.dist; a.rel_left = cfg.left_max; a.rel_right = cfg.right_max;
-    if (seq_attn_forward(a, st)) return 1;
+    if (dk == 64 && cfg.left_max + cfg.right_max + 1 <= 96) {
+      // the MFMA flash kernel with the distance term from an LDS table (attention.h): a 15 s prompt is 750 frames x 16 heads -- the
+      // one-wave-per-query kernel below took 0.7 ms per layer for it
+      AttnArgs fa;
+      fa.q = w.qkv; fa.k = w.qkv + D; fa.v = w.qkv + 2 * D; fa.o = w.att;
+      fa.q_bs = fa.k_bs = fa.v_bs = (long)T * 3 * D; fa.o_bs = (long)T * D;
+      fa.q_ts = fa.k_ts = fa.v_ts = 3 * D; fa.o_ts = D;
+      fa.B = B; fa.H = H; fa.Sq = T; fa.Sk = T; fa.causal = 0; fa.kend = w.len; fa.scale = att_scale;
+      fa.rel_key = L.dist; fa.rel_left = cfg.left_max; fa.rel_right = cfg.right_max;
+      fa.split_bf16 = get_gemm_mode() == GEMM_BF16X3;
+      if (flash_attn_forward(fa, st)) return 1;
+    } else {
+      SeqAttnArgs a;
+      a.q = w.qkv; a.k = w.qkv + D; a.v = w.qkv + 2 * D; a.ldq = a.ldk = a.ldv = 3 * D; a.q_bs = a.k_bs = a.v_bs = (long)T * 3 * D;
+      a.o = w.att; a.ldo = D; a.o_bs = (long)T * D; a.kend = w.len; a.B = B; a.H = H; a.Sq = T; a.Sk = T; a.dk = dk; a.scale = att_scale;
+      a.rel_key = L.dist; a.rel_left = cfg.left_max; a.rel_right = cfg.right_max;
+      if (seq_attn_forward(a, st)) return 1;
+    }
     if (lin(L.out, w.att, D, y, D, M, st, ACT_NONE, x, D)) return 1;
     std::swap(x, y);
     // convolution module

@@ -20,7 +20,7 @@ SYMBOLS = [
     "idxtts_fp8_e4m3_decode", "idxtts_fp8_e4m3_encode",
     "idxtts_bigvgan_create", "idxtts_bigvgan_workspace_bytes", "idxtts_bigvgan_fwd", "idxtts_bigvgan_fwd_ragged",
     "idxtts_profile_enable", "idxtts_profile_num_kernels", "idxtts_profile_kernel_name", "idxtts_profile_read", "idxtts_profile_event_overhead",
-    "idxtts_linear_create", "idxtts_linear_fwd", "idxtts_linear_destroy", "idxtts_release_stream", "idxtts_attention_fwd", "idxtts_attention_bf16x3_fwd", "idxtts_layernorm_fwd",
+    "idxtts_linear_create", "idxtts_linear_fwd", "idxtts_linear_destroy", "idxtts_release_stream", "idxtts_attention_fwd", "idxtts_attention_bf16x3_fwd", "idxtts_attention_relkey_fwd", "idxtts_layernorm_fwd",
     "idxtts_gpt_create", "idxtts_gpt_quantize_weights", "idxtts_gpt_set_kv_format", "idxtts_gpt_get_kv_format", "idxtts_gpt_workspace_bytes", "idxtts_gpt_embed", "idxtts_gpt_generate", "idxtts_gpt_generate_forced", "idxtts_gpt_generate_sampled", "idxtts_gpt_latent",
     "idxtts_gpt_beam_workspace_bytes", "idxtts_gpt_generate_beam",
     "idxtts_s2mel_create", "idxtts_s2mel_cond_workspace_bytes", "idxtts_s2mel_prepare_cond",
@@ -135,6 +135,8 @@ def load() -> ctypes.CDLL:
     lib.idxtts_attention_fwd.argtypes = [c_void_p] * 4 + [c_long, c_int, c_long, c_int, c_long, c_int, c_int, c_int, c_int, c_int,
                                                           c_int, c_void_p, c_void_p, c_float, c_void_p]
     lib.idxtts_attention_bf16x3_fwd.argtypes = lib.idxtts_attention_fwd.argtypes
+    lib.idxtts_attention_relkey_fwd.argtypes = [c_void_p] * 4 + [c_long, c_int, c_long, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_int,
+                                                                 c_int, c_void_p]
     lib.idxtts_layernorm_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]
     lib.idxtts_gpt_create.argtypes = [POINTER(GPTConfigC), POINTER(c_void_p)]
     lib.idxtts_gpt_workspace_bytes.argtypes = [c_void_p, c_int, c_int, c_int]

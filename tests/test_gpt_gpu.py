@@ -143,6 +143,33 @@ def test_attention_vs_torch(device, cfg):
         assert (got[~valid].abs().max().item() if (~valid).any() else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("B,H,S,left,right", [(2, 3, 300, 64, 8), (1, 2, 77, 64, 8), (2, 16, 750, 64, 8), (1, 1, 40, 5, 90), (2, 2, 129, 0, 0)])
+def test_attention_relative_key_vs_torch(device, B, H, S, left, right):
+    """The w2v-bert self-attention of the prompt block (HF Wav2Vec2BertSelfAttention, position_embeddings_type = "relative_key") on the MFMA
+    flash kernels: scores += q . rel_key[clamp(j - i, -left, right) + left] / sqrt(dk), right-padded keys masked; exact-fp32 and
+    split-bf16 forms against float64 torch."""
+    d = H * 64
+    qkv = torch.from_numpy(synth.uniform(f"t/attn/rel/qkv/{B}/{H}/{S}", (B, S, 3 * d), 1.0))
+    rel = torch.from_numpy(synth.uniform(f"t/attn/rel/tab/{left}/{right}", (left + right + 1, 64), 1.0))
+    kend = torch.tensor([S - 7 * b for b in range(B)], dtype=torch.int32)
+    q, k, v = [t.reshape(B, S, H, 64).transpose(1, 2).double() for t in qkv.split(d, dim=-1)]
+    pos = torch.arange(S)
+    dist = (pos[None, :] - pos[:, None]).clamp(-left, right) + left                       # [i, j] -> table row
+    scores = (q @ k.transpose(-1, -2) + torch.einsum("bhid,ijd->bhij", q, rel.double()[dist])) / 8.0
+    scores = scores.masked_fill(~(pos[None, :] < kend[:, None])[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(scores, -1) @ v).transpose(1, 2).reshape(B, S, d).float()
+    lib = _lib.load()
+    qd, rd, ke = qkv.to(device).contiguous(), rel.to(device).contiguous(), kend.to(device)
+    o = torch.empty(B, S, d, device=device)
+    base = qd.data_ptr()
+    for split, tol in ((0, 2e-5), (1, 1e-4)):
+        o.zero_()
+        _lib.check(lib.idxtts_attention_relkey_fwd(c_void_p(base), c_void_p(base + 4 * d), c_void_p(base + 8 * d), _lib.ptr(o), S * 3 * d, 3 * d,
+                                                   S * d, d, B, H, S, _lib.ptr(ke), 0.125, _lib.ptr(rd), left, right, split, _lib.current_stream()))
+        err = (o.cpu() - ref).abs().max().item()
+        assert err <= tol * max(1.0, ref.abs().max().item()), (split, err)
+
+
 def test_layernorm_vs_torch(device):
     for (M, d) in [(5, 128), (33, 1280), (4, 5120), (3, 512)]:
         x = torch.from_numpy(synth.uniform(f"t/ln/x/{M}/{d}", (M, d), 3.0, 0.7))
