@@ -39,7 +39,7 @@ int mask_rows(float* x, int M, int d, int T, const int* len, hipStream_t st);
 //   LayerNorm(D, eps 1e-5) * gamma + beta;  SiLU.   y [B*T][D]
 // pad_left < 0: (k-1)/2 (ESPnet "same" padding); pad_left = k-1: the causal form of Wav2Vec2BertConvolutionModule (all padding
 // on the left).  bdw may be null (depthwise conv without bias).
-int glu_dwconv_ln_silu(float* y, const float* pw, const float* wdw /* [D][k] */, const float* bdw, const float* gamma, const float* beta,
+int glu_dwconv_ln_silu(float* y, float* pw /* consumed: its a half is overwritten by a * sigmoid(gate) */, const float* wdw /* [D][k] */, const float* bdw, const float* gamma, const float* beta,
                        int B, int T, int D, int k, hipStream_t st, int pad_left = -1);
 
 // ConvNeXt block head (kmeans/vocos.py:507-517): depthwise Conv1d k ("same" zero padding) + bias over token-major rows x [B*T][D],

@@ -186,12 +186,22 @@ int mask_rows(float* x, int M, int d, int T, const int* len, hipStream_t st) {
 constexpr int DW_MAX_PER_THREAD = 4;    // D <= 1024
 
 // GLU: the input rows are [2D] = (a | gate) and the conv runs over a * sigmoid(gate); SILU: swish after the LayerNorm.
+// a * sigmoid(gate) of every [a | gate] row, written over a: ONE sigmoid per element (inside the depthwise loop it was evaluated once per
+// tap -- 31 times at w2v-bert's kernel size)
+__global__ __launch_bounds__(256) void glu_inplace_kernel(float* pw, int D, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const size_t m = i / D;
+  const int c = (int)(i - m * D);
+  float* row = pw + m * 2 * (size_t)D;
+  row[c] *= 1.0f / (1.0f + expf(-row[D + c]));
+}
+
 template <bool GLU, bool SILU>
 __global__ __launch_bounds__(256) void dwconv_ln_kernel(float* y, const float* pw, const float* wdw, const float* bdw, const float* gamma,
-                                                        const float* beta, int T, int D, int k, int pad, float eps) {
+                                                        const float* beta, int T, int D, int k, int pad, float eps, int ld) {
   __shared__ float red[4];
   const int m = blockIdx.x, b = m / T, t = m - b * T, tid = threadIdx.x;
-  const int ld = GLU ? 2 * D : D;
   float v[DW_MAX_PER_THREAD];
   float s = 0.0f;
 #pragma unroll
@@ -227,14 +237,18 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(float* y, const float* p
   }
 }
 
-int glu_dwconv_ln_silu(float* y, const float* pw, const float* wdw, const float* bdw, const float* gamma, const float* beta, int B, int T,
+int glu_dwconv_ln_silu(float* y, float* pw, const float* wdw, const float* bdw, const float* gamma, const float* beta, int B, int T,
                        int D, int k, hipStream_t st, int pad_left) {
   IDX_CHECK(y && pw && wdw && gamma && beta, "null pointer");
   IDX_CHECK(B > 0 && T > 0 && D > 0 && D <= 256 * DW_MAX_PER_THREAD && (k & 1) == 1 && pad_left < k, "shape");
   static const int cat = prof_register("dwconv_ln_kernel<true, true>");
   ProfScope prof(cat, st, 0.0, 4.0 * B * T * 3.0 * D);
-  hipLaunchKernelGGL((dwconv_ln_kernel<true, true>), dim3(B * T), dim3(256), 0, st, y, pw, wdw, bdw, gamma, beta, T, D, k,
-                     pad_left < 0 ? (k - 1) / 2 : pad_left, 1e-5f);
+  // the gated rows first, in place over the a half of pw (pw is this op's scratch input: consumed), then the depthwise taps over plain rows
+  const size_t n = (size_t)B * T * D;
+  hipLaunchKernelGGL(glu_inplace_kernel, dim3((unsigned)cdiv64((int64_t)n, 256)), dim3(256), 0, st, pw, D, n);
+  IDX_LAUNCH_CHECK();
+  hipLaunchKernelGGL((dwconv_ln_kernel<false, true>), dim3(B * T), dim3(256), 0, st, y, pw, wdw, bdw, gamma, beta, T, D, k,
+                     pad_left < 0 ? (k - 1) / 2 : pad_left, 1e-5f, 2 * D);
   IDX_LAUNCH_CHECK();
   return 0;
 }
@@ -245,7 +259,7 @@ int dwconv_ln(float* y, const float* x, const float* wdw, const float* bdw, cons
   IDX_CHECK(B > 0 && T > 0 && D > 0 && D <= 256 * DW_MAX_PER_THREAD && (k & 1) == 1, "shape");
   static const int cat = prof_register("dwconv_ln_kernel<false, false>");
   ProfScope prof(cat, st, 0.0, 4.0 * B * T * 2.0 * D);
-  hipLaunchKernelGGL((dwconv_ln_kernel<false, false>), dim3(B * T), dim3(256), 0, st, y, x, wdw, bdw, gamma, beta, T, D, k, (k - 1) / 2, eps);
+  hipLaunchKernelGGL((dwconv_ln_kernel<false, false>), dim3(B * T), dim3(256), 0, st, y, x, wdw, bdw, gamma, beta, T, D, k, (k - 1) / 2, eps, D);
   IDX_LAUNCH_CHECK();
   return 0;
 }
