@@ -668,6 +668,7 @@ int S2MelModel::cfm(const float* mu, const int* x_lens_host, const float* prompt
     pk.x_in = w.x_in; pk.ld = 2 * C + D + cfg.style_dim; pk.x = w.xstate; pk.prompt = prompt; pk.prompt_len = w.plen;
     pk.cond = w.condp; pk.cond_null = cond_proj.bias; pk.style = style;
     pk.B = B; pk.T = T; pk.C = C; pk.D = D; pk.S = cfg.style_dim; pk.Tp_max = Tp_max;
+    pk.x_only = s > 0;      // x_in is read by the merge GEMM and the long skip only: its other 784 columns are packed once
     if (cfm_pack(pk, st)) return 1;
     if (dit_eval_halves(*this, w, B, T, s, two_streams, st)) return 1;
     CfmEulerArgs eu;      // (two streams: the null half's estimate lives in half_view's second block)

@@ -16,6 +16,7 @@ struct CfmPackArgs {     // builds the 2B stacked [cond | null] DiT input rows (
   const float* cond_null;        // [D]      = cond_projection(0) = its bias
   const float* style;            // [B][S]
   int B, T, C, D, S, Tp_max;
+  int x_only = 0;                // 1: rewrite the x columns only (prompt, cond and style columns are the same at every Euler step)
 };
 int cfm_pack(const CfmPackArgs& a, hipStream_t st);
 

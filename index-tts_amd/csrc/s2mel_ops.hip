@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void cfm_pack_kernel(const CfmPackArgs p) {
   const int n = blockIdx.y, b = n % p.B;
   const bool is_cond = n < p.B;
   const int t0 = blockIdx.x * 64;
-  const int W = 2 * p.C + p.D + p.S;
+  const int W = p.x_only ? p.C : 2 * p.C + p.D + p.S;      // x_only: the columns that change from one Euler step to the next
   const int Tp = p.prompt_len[b];
   for (int e = threadIdx.x; e < 64 * W; e += 256) {
     const int tt = e / W, c = e - tt * W;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void cfm_pack_kernel(const CfmPackArgs p) {
 }
 
 int cfm_pack(const CfmPackArgs& a, hipStream_t st) {
-  const double bytes = 4.0 * 2 * a.B * (double)a.T * (2 * a.C + a.D + a.S) * 2;
+  const double bytes = 4.0 * 2 * a.B * (double)a.T * (a.x_only ? a.C : 2 * a.C + a.D + a.S) * 2;
   static const int cat = prof_register("cfm_pack_kernel");
   ProfScope prof(cat, st, 0.0, bytes);
   hipLaunchKernelGGL(cfm_pack_kernel, dim3(cdiv(a.T, 64), 2 * a.B), dim3(256), 0, st, a);
