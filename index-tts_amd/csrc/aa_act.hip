@@ -65,8 +65,7 @@ struct AAParams {
 // sin(x)^2: pi-periodic and even, so the argument is reduced to r in [-pi/2, pi/2] with a three-term Cody-Waite split of pi
 // (n * 3.140625 is exact for |n| < 2^15) and the sign never matters; degree-11 odd Taylor polynomial on r (|error| < 6e-8, the
 // size of libm's own).  A dozen instructions instead of sinf's ~40 with its large-argument path: the kernel was VALU-bound on it.
-__device__ __forceinline__ float sin_squared(float x) {
-  if (fabsf(x) > 1.0e5f) { const float s = sinf(x); return s * s; }      // never on audio-range activations
+__device__ __forceinline__ float sin_squared_fast(float x) {      // |x| <= 1e5 (the caller checks a whole group of arguments at once)
   const float n = rintf(x * 0.31830988618379067f);
   float r = fmaf(-n, 3.140625f, x);
   r = fmaf(-n, 9.67502593994140625e-4f, r);
@@ -80,8 +79,30 @@ __device__ __forceinline__ float sin_squared(float x) {
   return sn * sn;
 }
 
+__device__ __forceinline__ float sin_squared(float x) {
+  if (fabsf(x) > 1.0e5f) { const float s = sinf(x); return s * s; }      // never on audio-range activations
+  return sin_squared_fast(x);
+}
+
 __device__ __forceinline__ float snake(float u, float a, float inv_b) {
   return u + inv_b * sin_squared(u * a);
+}
+// eight activations at once: ONE range test for the group (a branch per value kept the eight polynomial chains from being interleaved and
+// cost three instructions each); the large-argument path (libm's sinf) is taken for the whole group or not at all -- same values either way
+__device__ __forceinline__ void snake8(float (&e)[4], float (&o)[4], const float (&ue)[4], const float (&uo)[4], float a, float inv_b) {
+  float amax = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fmaxf(fabsf(ue[i] * a), fabsf(uo[i] * a)));
+  if (amax > 1.0e5f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { e[i] = snake(ue[i], a, inv_b); o[i] = snake(uo[i], a, inv_b); }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      e[i] = ue[i] + inv_b * sin_squared_fast(ue[i] * a);
+      o[i] = uo[i] + inv_b * sin_squared_fast(uo[i] * a);
+    }
+  }
 }
 
 // RAGGED = false is the original single-length kernel (the hot path of equal-length batches); RAGGED = true adds the per-row
@@ -158,6 +179,7 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
       const f32x4 x1 = *reinterpret_cast<const f32x4*>(&xs[4 * G + 4]);
       const f32x4 x2 = *reinterpret_cast<const f32x4*>(&xs[4 * G + 8]);
       const float w[12] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3], x2[0], x2[1], x2[2], x2[3]};
+      float ue4[4], uo4[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         // j = jg+i ; x[j+2-q] = w[i+6-q] ; x[j+3-q] = w[i+7-q]
@@ -167,9 +189,10 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
           ue = fmaf(fe[q], w[i + 6 - q], ue);
           uo = fmaf(fo[q], w[i + 7 - q], uo);
         }
-        e[i] = snake(ue, a, inv_b);
-        o[i] = snake(uo, a, inv_b);
+        ue4[i] = ue;
+        uo4[i] = uo;
       }
+      snake8(e, o, ue4, uo4, a, inv_b);
     } else {
       // sequence edge: v is replicate-padded in ITS index space (m clamped to [0, 2T-1])
 #pragma unroll
