@@ -25,7 +25,9 @@
 
 namespace idxtts {
 
-constexpr int AA_TILE = 1024;   // outputs per tile (256 threads x 4)
+constexpr int AA_TILE = 1016;   // outputs per tile: 254 threads x 4, so that the (AA_TILE + 2 AA_VH) / 4 = 256 groups of the up-sampling phase are ONE
+                                // pass of the 256 threads (at 1024 outputs the 258 groups sent wave 0 through the whole phase a second time for two lanes:
+                                // an eighth of the kernel's VALU issue, and every other wave waited for it at the barrier)
 constexpr int AA_TPW = 4;       // consecutive tiles per workgroup (the next tile's loads overlap the current tile's arithmetic)
 constexpr int AA_XH = 8;        // x halo each side (>= 6 needed, 8 keeps float4 alignment)
 constexpr int AA_VH = 4;        // polyphase halo each side (>= 3 needed)
@@ -222,6 +224,7 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const AAParams p) {
 
   // ---- phase 3: polyphase down-sample, 4 outputs per thread ----
   const int t = t0 + 4 * tid;
+  if (4 * tid >= AA_TILE) continue;      // (the tile's last two threads have no outputs; the loop top's barrier is reached all the same)
   if (t >= Tstride) continue;    // (no barrier is skipped: the next tile of this row starts beyond Tstride too -> break above)
   if (RAGGED && t >= T) {        // padding of a shorter row inside a partly valid tile
 #pragma unroll
